@@ -1,0 +1,253 @@
+/* navtex_amd.h -- C ABI of libnavtex_amd.so
+ *
+ * MI355X-native NAVTEX demodulation hot path: int16 IQ in, 'B'/'Y' bits and
+ * SITOR-B characters out.  The decimating FIR cascade, the FSK discriminator
+ * and the bit-timing / mark-space matched filters run as HIP kernels on
+ * gfx950; the SITOR-B character layer runs on the host in C.
+ *
+ * Plain pointers and sizes only.  Every entry point cites the interface of the
+ * reference receiver (bartelvdh/Navtex, paths relative to its repo root) that
+ * it replaces or stands behind.  There is NO CPU fallback: device entry points
+ * return NVX_ERR_NODEV / NVX_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef NAVTEX_AMD_H
+#define NAVTEX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVX_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ errors */
+enum {
+    NVX_OK          =  0,
+    NVX_ERR_ARG     = -1,   /* bad argument / size not a multiple of the frame   */
+    NVX_ERR_NODEV   = -2,   /* no HIP device (this library has no CPU path)      */
+    NVX_ERR_HIP     = -3,   /* a HIP runtime call failed; see nvx_last_error()   */
+    NVX_ERR_NOMEM   = -4,
+    NVX_ERR_STATE   = -5,   /* call not valid in the handle's current mode       */
+    NVX_ERR_IO      = -6,   /* file errors of the WAV path                       */
+    NVX_ERR_FULL    = -7    /* staging ring cannot take the samples              */
+};
+NVX_API const char *nvx_last_error(void);
+NVX_API const char *nvx_version(void);
+
+/* ------------------------------------------------------------- rate algebra */
+#define NVX_RATE_RAW      2016000   /* receiver/capt_sched.c:31-34 H_SAMPLE_RATE          */
+#define NVX_RATE_IN        252000   /* receiver/capt_sched.c:29   IN_SAMPLE_RATE          */
+#define NVX_DECIM0              8   /* receiver/capt_sched.c:31   H_DECIMATION_FACTOR     */
+#define NVX_SPB_IN           2520   /* 252 kS/s samples per 100-baud bit                  */
+#define NVX_FRAME_BITS         32   /* device launch granule: 32 bit periods = 0.32 s     */
+#define NVX_FRAME_IN   (NVX_SPB_IN * NVX_FRAME_BITS)      /* 80 640 samples @252 kS/s     */
+#define NVX_FRAME_RAW  (NVX_FRAME_IN * NVX_DECIM0)        /* 645 120 samples @2.016 MS/s  */
+#define NVX_FRAME_Y3   (NVX_FRAME_BITS * 9)               /* 288 samples @900 S/s / chain */
+
+/* chain_mask bits: which of the two +-14 kHz chains of a stream are decoded
+ * (receiver/nav_sched.C:10-17 wires both; receiver/fir2cpp.C:112-128)       */
+#define NVX_CHAIN_518 1u    /* carrier at +14 kHz of the stream centre, mixed down */
+#define NVX_CHAIN_490 2u    /* carrier at -14 kHz of the stream centre, mixed up   */
+
+/* ==========================================================================
+ * A. Reference-compatible push surface.
+ *    Replaces receiver/fir1cpp.o fir2cpp.o fir3cpp.o decoder.o nav_b_sm.o
+ *    nav_sched.o at link time: an unmodified receiver/capt_sched.c calls these
+ *    three symbols (declarations capt_sched.c:17-19; calls :511, :554, :612).
+ *    Same contract: no return value, process-global singleton, one caller
+ *    thread.  Samples are buffered into frames and run on GPU 0; characters
+ *    leave through add_message().
+ * ========================================================================== */
+NVX_API void init_fir_filter1(void);                       /* receiver/fir1cpp.h:2  */
+NVX_API void sample_in_1(double sample_I, double sample_Q);/* receiver/fir1cpp.h:3  */
+NVX_API void init_fir2_wrapper(void);                      /* receiver/nav_sched.h:1 */
+
+/* Characters-out sink, receiver/message_store.h:7 (impl message_store.c:59-97).
+ * The library only CALLS this symbol.  A weak default that prints the message
+ * is provided so the library links stand-alone; the receiver's own
+ * message_store.o overrides it.                                             */
+int add_message(char *bbbb, char *message, int freq);
+
+/* Drains whatever the push surface has buffered so far in whole frames and
+ * waits for the GPU (the reference has no equivalent: it never terminates). */
+NVX_API int nvx_shim_flush(void);
+/* Bits the singleton has produced so far for chain 0 (518) / 1 (490).        */
+NVX_API size_t nvx_shim_bits(int chain, char *out, size_t cap);
+
+/* ==========================================================================
+ * B. SDRplay stream-callback shape, receiver/capt_sched.c:105
+ *      void StreamACallback(short *xi, short *xq, sdrplay_api_StreamCbParamsT
+ *           *params, unsigned int numSamples, unsigned int reset, void *ctx)
+ *    Planar int16 arrays owned by the caller, valid only during the call.
+ *    `params` is opaque here (sdrplay_api.h is vendor-proprietary), `reset`
+ *    and `params` are ignored exactly as the reference ignores them.
+ *    cbContext must be an nvx_handle* in push mode, or NULL for the singleton
+ *    of section A (stream 0).  Thread-safe against itself (the reference
+ *    serialises with a mutex, capt_sched.c:111,144).
+ * ========================================================================== */
+NVX_API void nvx_StreamACallback(short *xi, short *xq, void *params,
+                                 unsigned int numSamples, unsigned int reset, void *cbContext);
+
+/* ==========================================================================
+ * C. Block API (what A and B adapt onto).
+ * ========================================================================== */
+typedef struct nvx_handle nvx_handle;
+
+/* message sink; same argument meaning as add_message, plus the stream index */
+typedef void (*nvx_message_fn)(void *user, int stream, const char *bbbb, const char *message, int freq);
+
+typedef struct nvx_config {
+    int      device;          /* HIP device ordinal                                        */
+    int      n_streams;       /* independent IQ streams on this GPU                        */
+    int      raw_rate;        /* 1: input at 2.016 MS/s, integer stage 0 (/8) on device;   */
+                              /* 0: input at 252 kS/s exactly as StreamACallback delivers  */
+    uint32_t chain_mask;      /* default for every stream (NVX_CHAIN_518 | NVX_CHAIN_490)  */
+    const uint8_t *chain_masks; /* optional per-stream override, n_streams entries         */
+    const int *labels;        /* optional [n_streams][2] freq labels (default 518, 490)    */
+    int      max_frames;      /* largest number of frames one launch will be given         */
+    int      char_layer;      /* 1: run the host SITOR-B layer on the decoded bits         */
+    nvx_message_fn on_message;/* NULL: call add_message(bbbb, message, freq)               */
+    void    *user;
+    int      push_mode;       /* 1: allocate pinned staging for nvx_push_* (host input)    */
+} nvx_config;
+
+NVX_API void nvx_config_default(nvx_config *cfg);
+NVX_API int  nvx_create(const nvx_config *cfg, nvx_handle **out);
+NVX_API void nvx_destroy(nvx_handle *h);
+/* zero all carried DSP state (FIR histories, demodulator, character layer)  */
+NVX_API int  nvx_reset(nvx_handle *h);
+
+/* ---- host-input path (pinned staging + hipMemcpyAsync) -------------------
+ * Interleaved I,Q int16 (the layout of the reference's sample_buffer,
+ * capt_sched.c:120-129) or planar xi/xq (the callback's layout).  Samples are
+ * at the handle's input rate.  A launch happens whenever every stream has a
+ * whole frame staged.  Returns NVX_OK or NVX_ERR_FULL.                       */
+NVX_API int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq_interleaved, size_t n);
+NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n);
+/* wait for all launched work, deliver bits/messages                          */
+NVX_API int nvx_flush(nvx_handle *h);
+/* copy out and consume decoded bits ('B'/'Y') of one chain; returns count    */
+NVX_API size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, size_t cap);
+
+/* ---- device-resident path (roofline runs; IQ already in HBM) --------------
+ * d_iq: device pointer, int16 I,Q interleaved, layout [n_streams][pitch] in
+ * complex samples; stream s, frame f starts at d_iq + 4*(s*pitch + f*FRAME).
+ * Processes `n_frames` frames starting at frame `first_frame` of every stream
+ * on `hip_stream` (a hipStream_t; NULL = the handle's own stream), carrying
+ * state from the previous call.  Asynchronous; bits stay on the device until
+ * nvx_fetch_bits.                                                            */
+NVX_API int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch_samples,
+                                 size_t first_frame, int n_frames, void *hip_stream);
+/* synchronise, run the character layer (if enabled) on the new bits          */
+NVX_API int nvx_fetch_bits(nvx_handle *h);
+/* total bits decoded so far on (stream, chain) since create/reset            */
+NVX_API size_t nvx_bit_count(nvx_handle *h, int stream, int chain);
+
+/* ---- instrumentation -------------------------------------------------------
+ * HIP-event durations (ms) of the kernels of the most recent
+ * nvx_process_resident / push launch, measured on the launch stream:
+ * which = 0 FIR cascade, 1 demodulator.  Valid after a synchronise.          */
+NVX_API float nvx_last_kernel_ms(nvx_handle *h, int which);
+NVX_API void  nvx_enable_timing(nvx_handle *h, int enabled);
+/* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */
+NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
+/* debug tap: copy the 900 S/s FIR-cascade output of the LAST launch for one
+ * (stream, chain) to host: out[2*k], out[2*k+1] = I,Q; returns sample count  */
+NVX_API size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out, size_t cap_pairs);
+/* debug tap: discriminator output (delta-phi) of the last launch             */
+NVX_API size_t nvx_debug_dphi(nvx_handle *h, int stream, int chain, double *out, size_t cap);
+
+/* device memory helpers so callers need no HIP bindings of their own         */
+NVX_API int   nvx_device_count(void);
+NVX_API void *nvx_device_alloc(int device, size_t bytes);
+NVX_API void  nvx_device_free(int device, void *p);
+NVX_API int   nvx_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+NVX_API int   nvx_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+NVX_API int   nvx_device_sync(int device);
+
+/* ==========================================================================
+ * D. Host SITOR-B / CCIR-476 character layer
+ *    (receiver/nav_b_sm.h:56-128, receiver/nav_b_sm.C).  Stand-alone C; used
+ *    internally by C and exported for callers that bring their own bits.
+ * ========================================================================== */
+typedef struct nvx_sitor nvx_sitor;
+typedef void (*nvx_sitor_msg_fn)(void *user, const char *bbbb, const char *message, int freq);
+/* trace sink: receives the text the reference prints to stdout (may be NULL) */
+typedef void (*nvx_sitor_trace_fn)(void *user, const char *text);
+NVX_API nvx_sitor *nvx_sitor_new(int freq, nvx_sitor_msg_fn on_msg, void *user);
+NVX_API void nvx_sitor_set_trace(nvx_sitor *s, nvx_sitor_trace_fn fn, void *user);
+NVX_API void nvx_sitor_free(nvx_sitor *s);
+NVX_API void nvx_sitor_reset(nvx_sitor *s);
+NVX_API void nvx_sitor_receive_bit(nvx_sitor *s, char bit);            /* nav_b_sm.C:266 */
+NVX_API void nvx_sitor_receive_bits(nvx_sitor *s, const char *bits, size_t n);
+
+/* ==========================================================================
+ * E. WAV file path (receiver/wav.h:129-217 subset, 44-byte canonical PCM
+ *    header as receiver/wav.c writes it; 2 channels = I,Q, 16 bit, 252 kHz,
+ *    receiver/capt_sched.c:87-96).
+ * ========================================================================== */
+typedef struct nvx_wav nvx_wav;
+#define NVX_WAV_OPEN_READ  1
+#define NVX_WAV_OPEN_WRITE 2
+NVX_API nvx_wav *nvx_wav_open(const char *filename, uint32_t mode);    /* wav.h:129 */
+NVX_API int      nvx_wav_close(nvx_wav *w);                             /* wav.h:130 */
+NVX_API size_t   nvx_wav_read(nvx_wav *w, void *buffer, size_t frames); /* wav.h:141 */
+NVX_API size_t   nvx_wav_write(nvx_wav *w, const void *buffer, size_t frames); /* wav.h:151 */
+NVX_API void     nvx_wav_set_format(nvx_wav *w, uint16_t format);       /* wav.h:178 */
+NVX_API void     nvx_wav_set_num_channels(nvx_wav *w, uint16_t n);      /* wav.h:186 */
+NVX_API void     nvx_wav_set_sample_rate(nvx_wav *w, uint32_t rate);    /* wav.h:194 */
+NVX_API void     nvx_wav_set_sample_size(nvx_wav *w, size_t bytes);     /* wav.h:210 */
+NVX_API uint16_t nvx_wav_get_format(const nvx_wav *w);                  /* wav.h:212 */
+NVX_API uint16_t nvx_wav_get_num_channels(const nvx_wav *w);            /* wav.h:213 */
+NVX_API uint32_t nvx_wav_get_sample_rate(const nvx_wav *w);             /* wav.h:214 */
+NVX_API size_t   nvx_wav_get_sample_size(const nvx_wav *w);             /* wav.h:216 */
+NVX_API size_t   nvx_wav_get_length(const nvx_wav *w);                  /* wav.h:217, frames */
+NVX_API const char *nvx_wav_err(void);                                  /* wav.h:114 */
+/* File harness the reference lacks: open -> loop wav_read ->
+ * the capt_sched.c:509-513 loop, on the GPU.  The tail is zero-padded to a
+ * whole frame.  Returns number of frames processed or a negative error.      */
+NVX_API int nvx_decode_wav(nvx_handle *h, int stream, const char *filename);
+
+/* ==========================================================================
+ * F. Deterministic synthetic source (no reference counterpart).
+ *    Integer-only CPFSK modulator, bit-identical on host and device.
+ * ========================================================================== */
+/* SITOR-B transmit framing of `text` (A-Z 0-9 space and the CCIR-476 figure
+ * set, '\n' = CR LF): n_phasing (DX=0x4C, RX=0x07) pairs, DX/RX time diversity
+ * (RX repeats the DX character of two pairs earlier), three closing idle
+ * pairs.  Writes one byte per bit, 'B' or 'Y'; returns the bit count, or the
+ * needed capacity when bits == NULL.                                         */
+NVX_API size_t nvx_sitor_encode(const char *text, int n_phasing, char *bits, size_t cap);
+
+typedef struct nvx_carrier {
+    int32_t  freq_hz;        /* carrier offset from the stream centre (+14000 / -14000)   */
+    int32_t  shift_hz;       /* 'B' = freq+shift, 'Y' = freq-shift (85)                   */
+    int32_t  amplitude;      /* LSB                                                       */
+    uint32_t phase0;         /* initial phase, 2^32 = one turn                            */
+    uint32_t bit_offset;     /* samples by which bit boundaries lead n = 0, < samples/bit */
+    uint32_t n_bits;         /* bits[] length; the sequence repeats                       */
+    const char *bits;        /* 'B'/'Y' (host pointer)                                    */
+} nvx_carrier;
+
+typedef struct nvx_synth_stream {
+    uint32_t seed;
+    int32_t  noise_amp;      /* uniform integer noise in [-noise_amp, +noise_amp]         */
+    int32_t  n_carriers;     /* 0..2                                                      */
+    nvx_carrier carrier[2];
+} nvx_synth_stream;
+
+/* host generator: n complex samples starting at sample index n0, sample_rate
+ * NVX_RATE_RAW or NVX_RATE_IN, into out[2*n]                                 */
+NVX_API int nvx_synth_host(const nvx_synth_stream *s, uint32_t sample_rate,
+                           uint64_t n0, size_t n, int16_t *out_iq);
+/* device generator: fills d_out [n_streams][pitch] (complex samples) for
+ * sample indices [0, n) of every stream                                      */
+NVX_API int nvx_synth_device(int device, const nvx_synth_stream *streams, int n_streams,
+                             uint32_t sample_rate, size_t n, void *d_out, size_t pitch_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAVTEX_AMD_H */

@@ -1,0 +1,254 @@
+"""navtex_amd -- MI355X-native NAVTEX demodulation hot path.
+
+The product is the C-ABI shared library `libnavtex_amd.so` (HIP kernels for
+gfx950 + host C/C++, see include/navtex_amd.h).  This Python package is a thin
+ctypes mirror of that ABI for tests, bench.py and scripting; it contains no
+signal processing and no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRAME_Y3, RATE_IN, RATE_RAW,
+                      NvxError, lib)
+
+__all__ = ["Pipeline", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
+           "DeviceBuffer", "wav_write", "wav_read", "NvxError", "lib",
+           "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
+
+
+def device_count() -> int:
+    return lib.nvx_device_count()
+
+
+# ----------------------------------------------------------------- SITOR-B
+def sitor_encode(text: str, n_phasing: int = 40) -> str:
+    """SITOR-B transmit framing of `text` as a 'B'/'Y' string (nvx_sitor_encode)."""
+    t = text.encode("ascii")
+    n = lib.nvx_sitor_encode(t, n_phasing, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.nvx_sitor_encode(t, n_phasing, buf, n)
+    return buf.raw[:n].decode("ascii")
+
+
+class Sitor:
+    """Host character layer (nvx_sitor_*): bits in, (bbbb, message, freq) out."""
+
+    def __init__(self, freq: int = 518, trace: bool = False):
+        self.messages: List[Tuple[int, str, str]] = []
+        self.trace_text: List[str] = []
+        self._cb = N.SITOR_MSG_FN(lambda u, b, m, f: self.messages.append((f, b.decode("latin1"), m.decode("latin1"))))
+        self._h = lib.nvx_sitor_new(freq, self._cb, None)
+        if trace:
+            self._tcb = N.SITOR_TRACE_FN(lambda u, t: self.trace_text.append(t.decode("latin1")))
+            lib.nvx_sitor_set_trace(self._h, self._tcb, None)
+
+    def feed(self, bits: str) -> None:
+        b = bits.encode("ascii")
+        lib.nvx_sitor_receive_bits(self._h, b, len(b))
+
+    def trace(self) -> str:
+        return "".join(self.trace_text)
+
+    def close(self) -> None:
+        if self._h:
+            lib.nvx_sitor_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+# --------------------------------------------------------- synthetic source
+def make_stream(carriers: Sequence[dict], seed: int = 1, noise_amp: int = 1500) -> N.SynthStream:
+    """carriers: dicts with freq_hz, bits ('B'/'Y' str) and optional shift_hz (85),
+    amplitude (8000), phase0 (0), bit_offset (0)."""
+    s = N.SynthStream()
+    s.seed, s.noise_amp, s.n_carriers = seed & 0xFFFFFFFF, noise_amp, len(carriers)
+    s._keep = []
+    for i, c in enumerate(carriers):
+        bits = c["bits"].encode("ascii")
+        s._keep.append(bits)
+        cr = s.carrier[i]
+        cr.freq_hz, cr.shift_hz = int(c["freq_hz"]), int(c.get("shift_hz", 85))
+        cr.amplitude, cr.phase0 = int(c.get("amplitude", 8000)), int(c.get("phase0", 0)) & 0xFFFFFFFF
+        cr.bit_offset, cr.n_bits, cr.bits = int(c.get("bit_offset", 0)), len(bits), bits
+    return s
+
+
+def synth_host(stream: N.SynthStream, rate: int, n: int, n0: int = 0) -> np.ndarray:
+    """n complex samples as int16 [n, 2] (I, Q) from the host generator."""
+    out = np.empty((n, 2), dtype=np.int16)
+    N.check(lib.nvx_synth_host(C.byref(stream), rate, n0, n, N.as_ptr(out)), "nvx_synth_host")
+    return out
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by Python (through the C ABI, no HIP binding needed)."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = device, nbytes
+        self.ptr = lib.nvx_device_alloc(device, nbytes)
+        if not self.ptr:
+            raise NvxError(N.ERR_NOMEM, f"nvx_device_alloc({nbytes})")
+
+    def upload(self, a: np.ndarray, offset: int = 0) -> None:
+        a = np.ascontiguousarray(a)
+        N.check(lib.nvx_memcpy_h2d(self.device, self.ptr + offset, N.as_ptr(a), a.nbytes), "nvx_memcpy_h2d")
+
+    def download(self, nbytes: int, offset: int = 0, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        N.check(lib.nvx_memcpy_d2h(self.device, N.as_ptr(out), self.ptr + offset, out.nbytes), "nvx_memcpy_d2h")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            lib.nvx_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+def synth_device(streams: Sequence[N.SynthStream], rate: int, n: int, buf: DeviceBuffer, pitch: int) -> None:
+    arr = (N.SynthStream * len(streams))(*streams)
+    arr._keep = list(streams)
+    N.check(lib.nvx_synth_device(buf.device, arr, len(streams), rate, n, buf.ptr, pitch), "nvx_synth_device")
+
+
+# ------------------------------------------------------------------ pipeline
+class Pipeline:
+    """nvx_handle wrapper: the GPU receive pipeline for n_streams IQ streams."""
+
+    def __init__(self, n_streams: int = 1, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
+                 chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None,
+                 max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0):
+        self.messages: List[Tuple[int, int, str, str]] = []          # (stream, freq, bbbb, text)
+        cfg = N.Config()
+        lib.nvx_config_default(C.byref(cfg))
+        cfg.device, cfg.n_streams, cfg.raw_rate = device, n_streams, int(raw_rate)
+        cfg.chain_mask, cfg.max_frames, cfg.char_layer, cfg.push_mode = chain_mask, max_frames, int(char_layer), int(push_mode)
+        if chain_masks is not None:
+            self._masks = (C.c_uint8 * n_streams)(*list(chain_masks))
+            cfg.chain_masks = self._masks
+        if labels is not None:
+            flat = [int(v) for pair in labels for v in pair]
+            self._labels = (C.c_int * len(flat))(*flat)
+            cfg.labels = self._labels
+        self._cb = N.MESSAGE_FN(lambda u, s, b, m, f: self.messages.append((s, f, b.decode("latin1"), m.decode("latin1"))))
+        cfg.on_message = self._cb
+        self.n_streams, self.raw_rate, self.max_frames, self.device = n_streams, bool(raw_rate), max_frames, device
+        self.frame = FRAME_RAW if raw_rate else FRAME_IN
+        h = C.c_void_p()
+        N.check(lib.nvx_create(C.byref(cfg), C.byref(h)), "nvx_create")
+        self._h = h
+        self._bits = {}
+
+    # host input ---------------------------------------------------------
+    def push(self, stream: int, iq: np.ndarray) -> None:
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        N.check(lib.nvx_push_iq(self._h, stream, N.as_ptr(iq), iq.shape[0]), "nvx_push_iq")
+
+    def push_planar(self, stream: int, xi: np.ndarray, xq: np.ndarray) -> None:
+        xi = np.ascontiguousarray(xi, dtype=np.int16); xq = np.ascontiguousarray(xq, dtype=np.int16)
+        N.check(lib.nvx_push_planar(self._h, stream, N.as_ptr(xi), N.as_ptr(xq), xi.size), "nvx_push_planar")
+
+    def flush(self) -> None:
+        N.check(lib.nvx_flush(self._h), "nvx_flush")
+
+    def decode_wav(self, path: str, stream: int = 0) -> int:
+        return N.check(lib.nvx_decode_wav(self._h, stream, path.encode()), "nvx_decode_wav")
+
+    # resident input -------------------------------------------------------
+    def process_resident(self, buf: DeviceBuffer, pitch: int, first_frame: int, n_frames: int, hip_stream: int = 0) -> None:
+        N.check(lib.nvx_process_resident(self._h, buf.ptr, pitch, first_frame, n_frames, hip_stream or None),
+                "nvx_process_resident")
+
+    def fetch(self) -> None:
+        N.check(lib.nvx_fetch_bits(self._h), "nvx_fetch_bits")
+
+    # results ---------------------------------------------------------------
+    def bits(self, stream: int = 0, chain: int = 0) -> str:
+        """All bits decoded so far on (stream, chain)."""
+        key = (stream, chain)
+        cap = 1 << 16
+        buf = C.create_string_buffer(cap)
+        acc = self._bits.get(key, "")
+        while True:
+            n = lib.nvx_poll_bits(self._h, stream, chain, buf, cap)
+            acc += buf.raw[:n].decode("ascii")
+            if n < cap:
+                break
+        self._bits[key] = acc
+        return acc
+
+    def bit_count(self, stream: int = 0, chain: int = 0) -> int:
+        return lib.nvx_bit_count(self._h, stream, chain)
+
+    def reset(self) -> None:
+        N.check(lib.nvx_reset(self._h), "nvx_reset")
+        self._bits.clear()
+        self.messages.clear()
+
+    def enable_timing(self, on: bool = True) -> None:
+        lib.nvx_enable_timing(self._h, int(on))
+
+    def enable_debug(self, on: bool = True) -> None:
+        N.check(lib.nvx_enable_debug(self._h, int(on)), "nvx_enable_debug")
+
+    def kernel_ms(self, which: int) -> float:
+        return float(lib.nvx_last_kernel_ms(self._h, which))
+
+    def debug_y3(self, stream: int = 0, chain: int = 0) -> np.ndarray:
+        out = np.empty((self.max_frames * FRAME_Y3, 2), dtype=np.float64)
+        n = lib.nvx_debug_y3(self._h, stream, chain, N.as_ptr(out), out.shape[0])
+        return out[:n]
+
+    def debug_dphi(self, stream: int = 0, chain: int = 0) -> np.ndarray:
+        out = np.empty(self.max_frames * FRAME_Y3, dtype=np.float64)
+        n = lib.nvx_debug_dphi(self._h, stream, chain, N.as_ptr(out), out.size)
+        return out[:n]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.nvx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+# ----------------------------------------------------------------------- WAV
+def wav_write(path: str, iq: np.ndarray, rate: int = RATE_IN) -> None:
+    """2-channel 16-bit PCM, as receiver/capt_sched.c:87-96 configures its capture file."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+    w = lib.nvx_wav_open(path.encode(), 2)
+    if not w:
+        raise IOError(lib.nvx_wav_err().decode())
+    lib.nvx_wav_set_format(w, 1); lib.nvx_wav_set_num_channels(w, 2)
+    lib.nvx_wav_set_sample_rate(w, rate); lib.nvx_wav_set_sample_size(w, 2)
+    n = lib.nvx_wav_write(w, N.as_ptr(iq), iq.shape[0])
+    lib.nvx_wav_close(w)
+    if n != iq.shape[0]:
+        raise IOError("short WAV write")
+
+
+def wav_read(path: str) -> Tuple[np.ndarray, int]:
+    w = lib.nvx_wav_open(path.encode(), 1)
+    if not w:
+        raise IOError(lib.nvx_wav_err().decode())
+    n, ch, rate = lib.nvx_wav_get_length(w), lib.nvx_wav_get_num_channels(w), lib.nvx_wav_get_sample_rate(w)
+    out = np.empty((n, ch), dtype=np.int16)
+    got = lib.nvx_wav_read(w, N.as_ptr(out), n)
+    lib.nvx_wav_close(w)
+    return out[:got], rate

@@ -1,0 +1,104 @@
+"""ctypes binding of libnavtex_amd.so (the C ABI in include/navtex_amd.h).
+
+This module is plumbing for tests and bench.py: it adds no signal processing of
+its own and has no fallback -- if the native library is missing, import fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "libnavtex_amd.so"
+
+OK, ERR_ARG, ERR_NODEV, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_IO, ERR_FULL = 0, -1, -2, -3, -4, -5, -6, -7
+RATE_RAW, RATE_IN = 2016000, 252000
+FRAME_BITS, FRAME_IN, FRAME_RAW, FRAME_Y3 = 32, 80640, 645120, 288
+CHAIN_518, CHAIN_490 = 1, 2
+
+MESSAGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int)
+SITOR_MSG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int)
+SITOR_TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("n_streams", C.c_int), ("raw_rate", C.c_int), ("chain_mask", C.c_uint32),
+        ("chain_masks", C.POINTER(C.c_uint8)), ("labels", C.POINTER(C.c_int)), ("max_frames", C.c_int),
+        ("char_layer", C.c_int), ("on_message", MESSAGE_FN), ("user", C.c_void_p), ("push_mode", C.c_int),
+    ]
+
+
+class Carrier(C.Structure):
+    _fields_ = [
+        ("freq_hz", C.c_int32), ("shift_hz", C.c_int32), ("amplitude", C.c_int32), ("phase0", C.c_uint32),
+        ("bit_offset", C.c_uint32), ("n_bits", C.c_uint32), ("bits", C.c_char_p),
+    ]
+
+
+class SynthStream(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("noise_amp", C.c_int32), ("n_carriers", C.c_int32), ("carrier", Carrier * 2)]
+
+
+def _load() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -m navtex_amd.build` "
+            "(hipcc, gfx950). navtex_amd has no pure-Python or CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    vp, sz, i, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    sig = {
+        "nvx_last_error": (C.c_char_p, []), "nvx_version": (C.c_char_p, []),
+        "init_fir_filter1": (None, []), "sample_in_1": (None, [C.c_double, C.c_double]), "init_fir2_wrapper": (None, []),
+        "nvx_shim_flush": (i, []), "nvx_shim_bits": (sz, [i, C.c_char_p, sz]),
+        "nvx_StreamACallback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
+        "nvx_config_default": (None, [C.POINTER(Config)]),
+        "nvx_create": (i, [C.POINTER(Config), C.POINTER(vp)]), "nvx_destroy": (None, [vp]), "nvx_reset": (i, [vp]),
+        "nvx_push_iq": (i, [vp, i, vp, sz]), "nvx_push_planar": (i, [vp, i, vp, vp, sz]), "nvx_flush": (i, [vp]),
+        "nvx_poll_bits": (sz, [vp, i, i, C.c_char_p, sz]),
+        "nvx_process_resident": (i, [vp, vp, sz, sz, i, vp]), "nvx_fetch_bits": (i, [vp]),
+        "nvx_bit_count": (sz, [vp, i, i]),
+        "nvx_last_kernel_ms": (C.c_float, [vp, i]), "nvx_enable_timing": (None, [vp, i]), "nvx_enable_debug": (i, [vp, i]),
+        "nvx_debug_y3": (sz, [vp, i, i, vp, sz]), "nvx_debug_dphi": (sz, [vp, i, i, vp, sz]),
+        "nvx_device_count": (i, []), "nvx_device_alloc": (vp, [i, sz]), "nvx_device_free": (None, [i, vp]),
+        "nvx_memcpy_h2d": (i, [i, vp, vp, sz]), "nvx_memcpy_d2h": (i, [i, vp, vp, sz]), "nvx_device_sync": (i, [i]),
+        "nvx_sitor_new": (vp, [i, SITOR_MSG_FN, vp]), "nvx_sitor_set_trace": (None, [vp, SITOR_TRACE_FN, vp]),
+        "nvx_sitor_free": (None, [vp]), "nvx_sitor_reset": (None, [vp]),
+        "nvx_sitor_receive_bit": (None, [vp, C.c_char]), "nvx_sitor_receive_bits": (None, [vp, C.c_char_p, sz]),
+        "nvx_wav_open": (vp, [C.c_char_p, u32]), "nvx_wav_close": (i, [vp]),
+        "nvx_wav_read": (sz, [vp, vp, sz]), "nvx_wav_write": (sz, [vp, vp, sz]),
+        "nvx_wav_set_format": (None, [vp, C.c_uint16]), "nvx_wav_set_num_channels": (None, [vp, C.c_uint16]),
+        "nvx_wav_set_sample_rate": (None, [vp, u32]), "nvx_wav_set_sample_size": (None, [vp, sz]),
+        "nvx_wav_get_format": (C.c_uint16, [vp]), "nvx_wav_get_num_channels": (C.c_uint16, [vp]),
+        "nvx_wav_get_sample_rate": (u32, [vp]), "nvx_wav_get_sample_size": (sz, [vp]), "nvx_wav_get_length": (sz, [vp]),
+        "nvx_wav_err": (C.c_char_p, []), "nvx_decode_wav": (i, [vp, i, C.c_char_p]),
+        "nvx_sitor_encode": (sz, [C.c_char_p, i, C.c_char_p, sz]),
+        "nvx_synth_host": (i, [C.POINTER(SynthStream), u32, C.c_uint64, sz, vp]),
+        "nvx_synth_device": (i, [i, C.POINTER(SynthStream), i, u32, sz, vp, sz]),
+        "nvx_atan2_host": (C.c_double, [C.c_double, C.c_double]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTS = None  # filled lazily by tests from include/navtex_amd.h
+
+
+class NvxError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        super().__init__(f"{where}: error {code}: {lib.nvx_last_error().decode(errors='replace')}")
+
+
+def check(rc: int, where: str) -> int:
+    if rc < 0:
+        raise NvxError(rc, where)
+    return rc
+
+
+def as_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,88 @@
+"""Build helper: compiles libnavtex_amd.so (HIP kernels for gfx950 + host C/C++)
+in-tree with hipcc, and -- for tests only -- the oracle library and the compiled
+reference seams via oracle/Makefile.
+
+    python -m navtex_amd.build            # product library
+    python -m navtex_amd.build --oracle   # + oracle (and reference seams when /root/reference exists)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+OBJ = PKG / "_obj"
+LIB = PKG / "libnavtex_amd.so"
+ARCH = "gfx950"
+
+C_SOURCES = ["nvx_sitor.c", "nvx_wav.c", "nvx_synth_host.c"]
+HIP_SOURCES = ["nvx_kernels.hip"]
+CXX_SOURCES = ["nvx_api.cpp"]
+
+# -ffp-contract=off is part of the numerical contract: FIR products and sums are
+# rounded separately, exactly as the reference's x86-64 build does.
+COMMON = ["-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the HIP toolchain is required (there is no CPU build of this library)")
+
+
+def _run(cmd):
+    print(" ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], check=True)
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_lib(force: bool = False) -> Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [ROOT / "include" / "navtex_amd.h", Path(__file__)]
+    objs = []
+    for src in C_SOURCES:
+        o = OBJ / (src + ".o")
+        if force or _stale(o, [CSRC / src] + headers):
+            _run([hipcc, "-x", "c", "-std=gnu11", "-Wall", "-Wextra", *COMMON, "-c", CSRC / src, "-o", o])
+        objs.append(o)
+    for src in HIP_SOURCES:
+        o = OBJ / (src + ".o")
+        if force or _stale(o, [CSRC / src] + headers):
+            _run([hipcc, f"--offload-arch={ARCH}", "-std=c++17", *COMMON, "-c", CSRC / src, "-o", o])
+        objs.append(o)
+    for src in CXX_SOURCES:
+        o = OBJ / (src + ".o")
+        if force or _stale(o, [CSRC / src] + headers):
+            _run([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-std=c++17", "-Wall", "-Wno-unused-value", "-Wno-unused-result", *COMMON, "-c", CSRC / src, "-o", o])
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lpthread"])
+    return LIB
+
+
+def build_oracle() -> None:
+    """Test infrastructure: our CPU restatement, and the reference itself when its
+    sources are present (build container only)."""
+    _run(["make", "-s", "-C", ROOT / "oracle", "oracle"])
+    if Path("/root/reference/receiver").is_dir():
+        _run(["make", "-s", "-C", ROOT / "oracle", "ref"])
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)
+    if "--oracle" in sys.argv:
+        build_oracle()

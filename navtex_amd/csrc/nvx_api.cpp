@@ -1,0 +1,656 @@
+// nvx_api.cpp -- host runtime behind the C ABI of include/navtex_amd.h:
+// handle (device buffers, carried state, result ring), block API, pinned
+// staging for host input, reference-compatible push shim, SDRplay-shaped
+// callback adapter, WAV harness, device launcher of the synthetic source.
+//
+// There is no CPU implementation of the signal path in this library: every
+// entry point that needs the GPU returns NVX_ERR_NODEV / NVX_ERR_HIP without it
+// (and the void reference-shaped entry points print and abort()).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "navtex_amd.h"
+#include "nvx_internal.h"
+#include "nvx_kernels.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+extern "C" void nvx_set_error(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *nvx_last_error(void) { return g_err; }
+extern "C" const char *nvx_version(void) { return "navtex_amd 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            nvx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? NVX_ERR_NODEV : NVX_ERR_HIP; \
+        }                                                                                  \
+    } while (0)
+
+static int select_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        nvx_set_error("no HIP device available (%s); libnavtex_amd has no CPU path",
+                      e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return NVX_ERR_NODEV;
+    }
+    if (device < 0 || device >= n) { nvx_set_error("device %d out of range (0..%d)", device, n - 1); return NVX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    return NVX_OK;
+}
+
+// ------------------------------------------------------------------ handle
+static const int RESULT_SLOTS = 4;
+
+struct Slot {                          // one (stream, chain)
+    bool active = false;
+    int label = 0;
+    std::string bits;                  // everything decoded since create/reset
+    size_t polled = 0;                 // nvx_poll_bits cursor
+    nvx_sitor *sitor = nullptr;
+};
+
+struct Result {                        // one in-flight launch's bit output
+    uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
+    uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+struct nvx_handle {
+    nvx_config cfg{};
+    int n_streams = 0, n_slots = 0, nch = 1;
+    size_t frame_in = 0;               // complex input samples per frame at the input rate
+    int y3_cap = 0, bits_cap = 0;
+    hipStream_t stream = nullptr;
+    // device
+    uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
+    double2 *d_y3 = nullptr;
+    double *d_dd = nullptr, *d_dphi = nullptr; float *d_df = nullptr; int *d_di = nullptr;
+    Result res[RESULT_SLOTS];
+    uint64_t launched = 0, collected = 0;
+    int last_n3 = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
+    float ms[2] = { 0.f, 0.f };
+    bool ev_valid = false;
+    // host
+    std::vector<uint8_t> masks;
+    std::vector<Slot> slots;
+    std::mutex mu;
+    // push mode staging: two pinned sets [n_streams][stage_cap] of packed IQ words
+    uint32_t *h_stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_free[2] = { nullptr, nullptr };
+    bool stage_busy[2] = { false, false };
+    int cur = 0;
+    size_t stage_cap = 0;
+    std::vector<size_t> fill;
+    uint32_t *d_in = nullptr;
+};
+
+struct SinkCtx { nvx_handle *h; int stream; };
+
+static void sitor_sink(void *user, const char *bbbb, const char *message, int freq)
+{
+    SinkCtx *c = (SinkCtx *)user;
+    if (c->h->cfg.on_message) c->h->cfg.on_message(c->h->cfg.user, c->stream, bbbb, message, freq);
+    else add_message((char *)bbbb, (char *)message, freq);          // receiver/message_store.h:7
+}
+
+extern "C" __attribute__((weak, visibility("default"))) int add_message(char *bbbb, char *message, int freq)
+{
+    printf("[navtex_amd] message freq=%d bbbb=%s\n%s", freq, bbbb, message);
+    fflush(stdout);
+    return 0;
+}
+
+extern "C" void nvx_config_default(nvx_config *c)
+{
+    memset(c, 0, sizeof *c);
+    c->device = 0; c->n_streams = 1; c->raw_rate = 0;
+    c->chain_mask = NVX_CHAIN_518 | NVX_CHAIN_490;
+    c->max_frames = 1; c->char_layer = 1; c->push_mode = 0;
+}
+
+static void free_handle(nvx_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3);
+    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in);
+    for (auto &r : h->res) {
+        hipFree(r.d_bits); hipFree(r.d_nbits);
+        if (r.h_bits) hipHostFree(r.h_bits);
+        if (r.h_nbits) hipHostFree(r.h_nbits);
+        if (r.done) hipEventDestroy(r.done);
+    }
+    for (int i = 0; i < 3; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 2; i++) {
+        if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
+        if (h->stage_free[i]) hipEventDestroy(h->stage_free[i]);
+    }
+    for (auto &s : h->slots) {
+        if (s.sitor) nvx_sitor_free(s.sitor);
+    }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" void nvx_destroy(nvx_handle *h) { free_handle(h); }
+
+static std::vector<SinkCtx *> &sink_pool() { static std::vector<SinkCtx *> p; return p; }
+
+extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
+{
+    if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1) { nvx_set_error("nvx_create: bad config"); return NVX_ERR_ARG; }
+    *out = nullptr;
+    int rc = select_device(cfg->device);
+    if (rc != NVX_OK) return rc;
+
+    nvx_handle *h = new nvx_handle();
+    h->cfg = *cfg;
+    h->n_streams = cfg->n_streams; h->n_slots = 2 * cfg->n_streams;
+    h->frame_in = cfg->raw_rate ? (size_t)NVX_FRAME_RAW : (size_t)NVX_FRAME_IN;
+    h->y3_cap = cfg->max_frames * NVX_FRAME_Y3;
+    h->bits_cap = h->y3_cap / 8 + 8;            // a bit needs >= 8 samples (offset slews by at most 1)
+    h->masks.resize(h->n_streams);
+    h->slots.resize(h->n_slots);
+    bool any_two = false;
+    for (int s = 0; s < h->n_streams; s++) {
+        uint8_t m = cfg->chain_masks ? cfg->chain_masks[s] : (uint8_t)cfg->chain_mask;
+        m &= 3;
+        if (!m) { nvx_set_error("nvx_create: stream %d has an empty chain mask", s); delete h; return NVX_ERR_ARG; }
+        h->masks[s] = m;
+        if (m == 3) any_two = true;
+        for (int c = 0; c < 2; c++) {
+            Slot &sl = h->slots[2 * s + c];
+            sl.active = (m >> c) & 1;
+            sl.label = cfg->labels ? cfg->labels[2 * s + c] : (c == 0 ? 518 : 490);
+            if (sl.active && cfg->char_layer) {
+                SinkCtx *ctx = new SinkCtx{ h, s };
+                sink_pool().push_back(ctx);         // lives as long as the process (tiny)
+                sl.sitor = nvx_sitor_new(sl.label, sitor_sink, ctx);
+            }
+        }
+    }
+    h->nch = any_two ? 2 : 1;
+
+#define CR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+        nvx_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); free_handle(h); \
+        return e_ == hipErrorOutOfMemory ? NVX_ERR_NOMEM : NVX_ERR_HIP; } } while (0)
+
+    CR_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    std::vector<uint8_t> active(h->n_slots);
+    for (int i = 0; i < h->n_slots; i++) active[i] = h->slots[i].active;
+    CR_TRY(hipMalloc(&h->d_masks, h->n_streams));
+    CR_TRY(hipMalloc(&h->d_active, h->n_slots));
+    CR_TRY(hipMemcpy(h->d_masks, h->masks.data(), h->n_streams, hipMemcpyHostToDevice));
+    CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
+    CR_TRY(hipMalloc(&h->d_cstate, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
+    CR_TRY(hipMalloc(&h->d_y3, (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
+    CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
+    CR_TRY(hipMalloc(&h->d_df, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float)));
+    CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
+    for (auto &r : h->res) {
+        CR_TRY(hipMalloc(&r.d_bits, (size_t)h->n_slots * h->bits_cap));
+        CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
+        CR_TRY(hipHostMalloc((void **)&r.h_bits, (size_t)h->n_slots * h->bits_cap, hipHostMallocDefault));
+        CR_TRY(hipHostMalloc((void **)&r.h_nbits, (size_t)h->n_slots * sizeof(int), hipHostMallocDefault));
+        CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+    }
+    for (int i = 0; i < 3; i++) CR_TRY(hipEventCreate(&h->ev[i]));
+    if (cfg->push_mode) {
+        h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
+        for (int i = 0; i < 2; i++) {
+            CR_TRY(hipHostMalloc((void **)&h->h_stage[i], (size_t)h->n_streams * h->stage_cap * 4, hipHostMallocDefault));
+            CR_TRY(hipEventCreateWithFlags(&h->stage_free[i], hipEventDisableTiming));
+        }
+        CR_TRY(hipMalloc(&h->d_in, (size_t)h->n_streams * cfg->max_frames * h->frame_in * 4));
+        h->fill.assign(h->n_streams, 0);
+    }
+#undef CR_TRY
+    rc = nvx_reset(h);
+    if (rc != NVX_OK) { free_handle(h); return rc; }
+    *out = h;
+    return NVX_OK;
+}
+
+static int collect_locked(nvx_handle *h);
+
+extern "C" int nvx_reset(nvx_handle *h)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto &r : h->res) r.pending = false;
+    h->collected = h->launched;
+    HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_df, 0, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float), h->stream));
+    // ints: all zero except prev_offset = -1 (decoder.C:30)
+    std::vector<int> ints((size_t)NVX_DEMOD_INTS * h->n_slots, 0);
+    for (int i = 0; i < h->n_slots; i++) ints[(size_t)NVX_DI_PREV_OFFSET * h->n_slots + i] = -1;
+    HIP_TRY(hipMemcpyAsync(h->d_di, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto &s : h->slots) { s.bits.clear(); s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
+    if (!h->fill.empty()) std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
+    return NVX_OK;
+}
+
+// launch cascade + demod over n_frames frames of [n_streams][pitch] packed IQ
+static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st)
+{
+    if (n_frames < 1 || n_frames > h->cfg.max_frames) { nvx_set_error("n_frames %d outside 1..max_frames %d", n_frames, h->cfg.max_frames); return NVX_ERR_ARG; }
+    if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
+    Result &r = h->res[h->launched % RESULT_SLOTS];
+    if (r.pending) { int rc = collect_locked(h); if (rc != NVX_OK) return rc; }
+
+    nvx_cascade_args ca{};
+    ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
+    ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
+    ca.state = h->d_cstate; ca.y3 = h->d_y3; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    nvx_demod_args da{};
+    da.y3 = h->d_y3; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
+    da.n_slots = h->n_slots; da.slot_active = h->d_active;
+    da.state_d = h->d_dd; da.state_f = h->d_df; da.state_i = h->d_di;
+    da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
+
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], st));
+    HIP_TRY(nvx_launch_cascade(&ca, h->cfg.raw_rate, h->nch, st));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], st));
+    HIP_TRY(nvx_launch_demod(&da, st));
+    if (h->timing) { HIP_TRY(hipEventRecord(h->ev[2], st)); h->ev_valid = true; }
+    HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(r.done, st));
+    r.pending = true;
+    h->launched++;
+    h->last_n3 = da.n3;
+    return NVX_OK;
+}
+
+// wait for every launched block, append bits, run the character layer
+static int collect_locked(nvx_handle *h)
+{
+    while (h->collected < h->launched) {
+        Result &r = h->res[h->collected % RESULT_SLOTS];
+        if (r.pending) {
+            HIP_TRY(hipEventSynchronize(r.done));
+            for (int i = 0; i < h->n_slots; i++) {
+                Slot &s = h->slots[i];
+                if (!s.active) continue;
+                int n = r.h_nbits[i];
+                if (n > h->bits_cap) { nvx_set_error("bit buffer overflow on slot %d (%d > %d)", i, n, h->bits_cap); return NVX_ERR_STATE; }
+                const char *b = (const char *)r.h_bits + (size_t)i * h->bits_cap;
+                s.bits.append(b, (size_t)n);
+                if (s.sitor) nvx_sitor_receive_bits(s.sitor, b, (size_t)n);
+            }
+            r.pending = false;
+        }
+        h->collected++;
+    }
+    return NVX_OK;
+}
+
+extern "C" int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_frame, int n_frames, void *hip_stream)
+{
+    if (!h || !d_iq) { nvx_set_error("nvx_process_resident: null argument"); return NVX_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    return launch_locked(h, d_iq, pitch, first_frame * h->frame_in, n_frames, st);
+}
+
+extern "C" int nvx_fetch_bits(nvx_handle *h)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = collect_locked(h);
+    if (rc == NVX_OK && h->timing && h->ev_valid) {
+        hipEventSynchronize(h->ev[2]);
+        hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[1]);
+        hipEventElapsedTime(&h->ms[1], h->ev[1], h->ev[2]);
+    }
+    return rc;
+}
+
+extern "C" size_t nvx_bit_count(nvx_handle *h, int stream, int chain)
+{
+    if (!h || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return h->slots[2 * stream + chain].bits.size();
+}
+
+extern "C" size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, size_t cap)
+{
+    if (!h || !out || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    Slot &s = h->slots[2 * stream + chain];
+    size_t n = std::min(cap, s.bits.size() - s.polled);
+    memcpy(out, s.bits.data() + s.polled, n);
+    s.polled += n;
+    return n;
+}
+
+extern "C" void nvx_enable_timing(nvx_handle *h, int enabled) { if (h) h->timing = enabled != 0; }
+extern "C" float nvx_last_kernel_ms(nvx_handle *h, int which) { return (h && which >= 0 && which < 2) ? h->ms[which] : -1.f; }
+
+extern "C" int nvx_enable_debug(nvx_handle *h, int enabled)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (enabled && !h->d_dphi) HIP_TRY(hipMalloc(&h->d_dphi, (size_t)h->n_slots * h->y3_cap * sizeof(double)));
+    if (!enabled && h->d_dphi) { hipFree(h->d_dphi); h->d_dphi = nullptr; }
+    return NVX_OK;
+}
+
+extern "C" size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out, size_t cap_pairs)
+{
+    if (!h || !out || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    size_t n = std::min(cap_pairs, (size_t)h->last_n3);
+    if (hipMemcpy(out, h->d_y3 + (size_t)(2 * stream + chain) * h->y3_cap, n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" size_t nvx_debug_dphi(nvx_handle *h, int stream, int chain, double *out, size_t cap)
+{
+    if (!h || !out || !h->d_dphi || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    size_t n = std::min(cap, (size_t)h->last_n3);
+    if (hipMemcpy(out, h->d_dphi + (size_t)(2 * stream + chain) * h->y3_cap, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------- host-input path
+// Submit the largest common whole-frame prefix of the current staging set.
+static int submit_locked(nvx_handle *h)
+{
+    size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
+    int frames = (int)std::min<size_t>(minfill / h->frame_in, (size_t)h->cfg.max_frames);
+    if (frames < 1) return NVX_OK;
+    const int cur = h->cur, nxt = cur ^ 1;
+    const size_t take = (size_t)frames * h->frame_in;
+    const size_t dpitch = (size_t)h->cfg.max_frames * h->frame_in;
+    // the other staging set must have left the copy engine before it is refilled
+    if (h->stage_busy[nxt]) { HIP_TRY(hipEventSynchronize(h->stage_free[nxt])); h->stage_busy[nxt] = false; }
+    // d_in is reused by every launch: stream order makes the previous kernels finish first
+    HIP_TRY(hipMemcpy2DAsync(h->d_in, dpitch * 4, h->h_stage[cur], h->stage_cap * 4, take * 4, (size_t)h->n_streams,
+                             hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->stage_free[cur], h->stream));
+    h->stage_busy[cur] = true;
+    int rc = launch_locked(h, h->d_in, dpitch, 0, frames, h->stream);
+    if (rc != NVX_OK) return rc;
+    // carry what was not submitted over to the other set
+    for (int s = 0; s < h->n_streams; s++) {
+        size_t rest = h->fill[s] - take;
+        if (rest) memcpy(h->h_stage[nxt] + (size_t)s * h->stage_cap, h->h_stage[cur] + (size_t)s * h->stage_cap + take, rest * 4);
+        h->fill[s] = rest;
+    }
+    h->cur = nxt;
+    return NVX_OK;
+}
+
+template <typename F>
+static int push_common(nvx_handle *h, int stream, size_t n, F copy_in)
+{
+    if (!h || stream < 0 || stream >= h->n_streams) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
+    if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    size_t done = 0;
+    while (done < n) {
+        size_t room = h->stage_cap - h->fill[stream];
+        if (room == 0) {
+            int rc = submit_locked(h);
+            if (rc != NVX_OK) return rc;
+            room = h->stage_cap - h->fill[stream];
+            if (room == 0) { nvx_set_error("stream %d is a whole staging buffer ahead of the slowest stream", stream); return NVX_ERR_FULL; }
+        }
+        size_t m = std::min(room, n - done);
+        copy_in(h->h_stage[h->cur] + (size_t)stream * h->stage_cap + h->fill[stream], done, m);
+        h->fill[stream] += m;
+        done += m;
+        size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
+        if (minfill >= h->frame_in) { int rc = submit_locked(h); if (rc != NVX_OK) return rc; }
+    }
+    return NVX_OK;
+}
+
+extern "C" int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq, size_t n)
+{
+    return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) { memcpy(dst, iq + 2 * off, m * 4); });
+}
+
+extern "C" int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n)
+{
+    return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) {
+        for (size_t k = 0; k < m; k++)                     // interleave as capt_sched.c:120-129 does
+            dst[k] = (uint32_t)(uint16_t)xi[off + k] | ((uint32_t)(uint16_t)xq[off + k] << 16);
+    });
+}
+
+extern "C" int nvx_flush(nvx_handle *h)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->cfg.push_mode) {
+        for (;;) {
+            size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
+            if (minfill < h->frame_in) break;
+            int rc = submit_locked(h);
+            if (rc != NVX_OK) return rc;
+        }
+    }
+    return collect_locked(h);
+}
+
+// ------------------------------------------------------------ device helpers
+extern "C" int nvx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+extern "C" void *nvx_device_alloc(int device, size_t bytes)
+{
+    if (select_device(device) != NVX_OK) return nullptr;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { nvx_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+extern "C" void nvx_device_free(int device, void *p) { if (p && select_device(device) == NVX_OK) hipFree(p); }
+extern "C" int nvx_memcpy_h2d(int device, void *d, const void *s, size_t n)
+{
+    int rc = select_device(device); if (rc != NVX_OK) return rc;
+    HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return NVX_OK;
+}
+extern "C" int nvx_memcpy_d2h(int device, void *d, const void *s, size_t n)
+{
+    int rc = select_device(device); if (rc != NVX_OK) return rc;
+    HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return NVX_OK;
+}
+extern "C" int nvx_device_sync(int device)
+{
+    int rc = select_device(device); if (rc != NVX_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize()); return NVX_OK;
+}
+
+// ------------------------------------------------------------ synthetic source
+extern "C" int nvx_synth_device(int device, const nvx_synth_stream *streams, int n_streams,
+                                uint32_t sample_rate, size_t n, void *d_out, size_t pitch)
+{
+    if (!streams || n_streams < 1 || !d_out || (sample_rate != NVX_RATE_RAW && sample_rate != NVX_RATE_IN) || pitch < n || (pitch & 3)) {
+        nvx_set_error("nvx_synth_device: bad argument"); return NVX_ERR_ARG;
+    }
+    int rc = select_device(device); if (rc != NVX_OK) return rc;
+    const uint32_t spb = sample_rate / 100;
+    std::vector<nvx_synth_desc> desc(n_streams);
+    std::vector<nvx_period> pool;
+    for (int s = 0; s < n_streams; s++) {
+        const nvx_synth_stream &st = streams[s];
+        if (st.n_carriers < 0 || st.n_carriers > 2) { nvx_set_error("nvx_synth_device: stream %d: bad carrier count", s); return NVX_ERR_ARG; }
+        nvx_synth_desc &d = desc[s];
+        memset(&d, 0, sizeof d);
+        d.seed = st.seed; d.noise_amp = st.noise_amp; d.n_carriers = st.n_carriers;
+        for (int c = 0; c < st.n_carriers; c++) {
+            if (st.carrier[c].bit_offset >= spb) { nvx_set_error("nvx_synth_device: bit_offset >= samples per bit"); return NVX_ERR_ARG; }
+            size_t periods = (n + st.carrier[c].bit_offset) / spb + 2;
+            d.amp[c] = st.carrier[c].amplitude; d.bit_offset[c] = st.carrier[c].bit_offset;
+            d.pool_off[c] = (uint32_t)pool.size();
+            pool.resize(pool.size() + periods);
+            nvx_synth_periods(&st.carrier[c], sample_rate, 0, periods, pool.data() + d.pool_off[c]);
+        }
+    }
+    nvx_synth_desc *d_desc = nullptr; nvx_period *d_pool = nullptr;
+    HIP_TRY(hipMalloc(&d_desc, desc.size() * sizeof(nvx_synth_desc)));
+    hipError_t e = hipMalloc(&d_pool, std::max<size_t>(pool.size(), 1) * sizeof(nvx_period));
+    if (e != hipSuccess) { hipFree(d_desc); nvx_set_error("hipMalloc pool failed: %s", hipGetErrorString(e)); return NVX_ERR_NOMEM; }
+    hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(nvx_synth_desc), hipMemcpyHostToDevice);
+    if (!pool.empty()) hipMemcpy(d_pool, pool.data(), pool.size() * sizeof(nvx_period), hipMemcpyHostToDevice);
+    nvx_synth_args a{};
+    a.desc = d_desc; a.pool = d_pool; a.out = (uint32_t *)d_out; a.pitch = pitch; a.n = n; a.spb = spb;
+    e = nvx_launch_synth(&a, n_streams, nullptr);
+    hipError_t e2 = hipDeviceSynchronize();
+    hipFree(d_desc); hipFree(d_pool);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        nvx_set_error("synth kernel failed: %s", hipGetErrorString(e != hipSuccess ? e : e2)); return NVX_ERR_HIP;
+    }
+    return NVX_OK;
+}
+
+// ------------------------------------------------------------------ WAV path
+extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
+{
+    if (!h || !filename) { nvx_set_error("nvx_decode_wav: null argument"); return NVX_ERR_ARG; }
+    if (!h->cfg.push_mode) { nvx_set_error("nvx_decode_wav: handle needs push_mode"); return NVX_ERR_STATE; }
+    nvx_wav *w = nvx_wav_open(filename, NVX_WAV_OPEN_READ);
+    if (!w) { nvx_set_error("nvx_decode_wav: %s", nvx_wav_err()); return NVX_ERR_IO; }
+    const uint32_t want = h->cfg.raw_rate ? NVX_RATE_RAW : NVX_RATE_IN;
+    if (nvx_wav_get_num_channels(w) != 2 || nvx_wav_get_sample_size(w) != 2 || nvx_wav_get_format(w) != 1 ||
+        nvx_wav_get_sample_rate(w) != want) {
+        nvx_set_error("nvx_decode_wav: need 2-channel 16-bit PCM at %u Hz (capt_sched.c:91-95)", want);
+        nvx_wav_close(w); return NVX_ERR_IO;
+    }
+    std::vector<int16_t> buf(2 * 65536);
+    size_t total = 0, got;
+    int rc = NVX_OK;
+    while ((got = nvx_wav_read(w, buf.data(), 65536)) > 0) {
+        rc = nvx_push_iq(h, stream, buf.data(), got);
+        if (rc != NVX_OK) break;
+        total += got;
+    }
+    nvx_wav_close(w);
+    if (rc != NVX_OK) return rc;
+    size_t pad = (h->frame_in - total % h->frame_in) % h->frame_in;       // silence up to a whole frame
+    std::fill(buf.begin(), buf.end(), (int16_t)0);
+    while (pad) {
+        size_t m = std::min<size_t>(pad, 65536);
+        rc = nvx_push_iq(h, stream, buf.data(), m);
+        if (rc != NVX_OK) return rc;
+        pad -= m;
+    }
+    rc = nvx_flush(h);
+    if (rc != NVX_OK) return rc;
+    return (int)((total + h->frame_in - 1) / h->frame_in);
+}
+
+// ===========================================================================
+// reference-compatible push surface + stream callback (sections A, B)
+// ===========================================================================
+static nvx_handle *g_shim = nullptr;
+static std::mutex g_shim_mu;                     // callback re-entrancy (capt_sched.c:111)
+static int16_t g_shim_buf[2 * 4096];
+static size_t g_shim_n = 0;
+
+static void shim_fatal(const char *what)
+{
+    fprintf(stderr, "navtex_amd: %s: %s\n", what, nvx_last_error());
+    abort();                                     // void reference entry points cannot report errors
+}
+
+static void shim_require(void)
+{
+    if (g_shim) return;
+    nvx_config c; nvx_config_default(&c);
+    c.n_streams = 1; c.raw_rate = 0; c.chain_mask = NVX_CHAIN_518 | NVX_CHAIN_490;   // nav_sched.C:10-17
+    c.max_frames = 4; c.char_layer = 1; c.push_mode = 1;
+    if (const char *d = getenv("NAVTEX_AMD_DEVICE")) c.device = atoi(d);
+    if (nvx_create(&c, &g_shim) != NVX_OK) shim_fatal("cannot create the GPU pipeline");
+}
+
+static void shim_drain(void)
+{
+    if (g_shim_n && nvx_push_iq(g_shim, 0, g_shim_buf, g_shim_n) != NVX_OK) shim_fatal("push failed");
+    g_shim_n = 0;
+}
+
+extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    shim_require();
+    g_shim_n = 0;
+    if (nvx_reset(g_shim) != NVX_OK) shim_fatal("reset failed");
+}
+
+extern "C" void init_fir2_wrapper(void)          // receiver/nav_sched.C:19-22
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    shim_require();                              // the object graph already exists; nothing else to wire
+}
+
+extern "C" void sample_in_1(double sample_I, double sample_Q)   // receiver/fir1cpp.C:80
+{
+    // capt_sched.c:511 passes (double) of int16 values; the cast back is exact
+    if (!g_shim) { std::lock_guard<std::mutex> lk(g_shim_mu); shim_require(); }
+    g_shim_buf[2 * g_shim_n] = (int16_t)sample_I;
+    g_shim_buf[2 * g_shim_n + 1] = (int16_t)sample_Q;
+    if (++g_shim_n == 4096) shim_drain();
+}
+
+extern "C" int nvx_shim_flush(void)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (!g_shim) { nvx_set_error("shim not initialised"); return NVX_ERR_STATE; }
+    shim_drain();
+    return nvx_flush(g_shim);
+}
+
+extern "C" size_t nvx_shim_bits(int chain, char *out, size_t cap)
+{
+    if (!g_shim) return 0;
+    return nvx_poll_bits(g_shim, 0, chain, out, cap);
+}
+
+extern "C" void nvx_StreamACallback(short *xi, short *xq, void *params, unsigned int numSamples,
+                                    unsigned int reset, void *cbContext)
+{
+    (void)params; (void)reset;                   // ignored by the reference too (capt_sched.c:105-148)
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    nvx_handle *h = (nvx_handle *)cbContext;
+    if (!h) { shim_require(); shim_drain(); h = g_shim; }
+    if (nvx_push_planar(h, 0, xi, xq, numSamples) != NVX_OK) shim_fatal("stream callback push failed");
+}

@@ -1,0 +1,58 @@
+/* nvx_kernels.h -- argument blocks of the gfx950 kernels (internal). */
+#ifndef NVX_KERNELS_H
+#define NVX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nvx_synth.h"
+
+#define NVX_PASSES_PER_FRAME 315          /* 20160 FIR1 outputs per frame / 64 per pass */
+/* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
+ * outputs and 70 FIR2 outputs, all fp64 pairs                                 */
+#define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70))
+#define NVX_CASCADE_STATE_BYTES   (NVX_CASCADE_STATE_ENTRIES * 16)
+#define NVX_DEMOD_DOUBLES (2 + 9 + 9 + 567)
+#define NVX_DEMOD_FLOATS  4
+#define NVX_DEMOD_INTS    14
+#define NVX_DI_PREV_OFFSET 12           /* int field that resets to -1 (decoder.C:30) */
+
+typedef struct {
+    const uint32_t *iq;        /* [n_streams][pitch] packed int16 I | Q<<16            */
+    size_t pitch;              /* complex samples between streams                      */
+    size_t first_sample;       /* first complex sample of this launch in every stream  */
+    int n_frames;
+    int n_streams;
+    const uint8_t *chain_masks;
+    uint8_t *state;            /* [n_streams][NVX_CASCADE_STATE_BYTES]                 */
+    double2 *y3;               /* [n_streams*2][y3_cap]                                */
+    size_t y3_cap, y3_base;
+} nvx_cascade_args;
+
+typedef struct {
+    const double2 *y3;
+    size_t y3_cap, y3_base;
+    int n3;                    /* 900 S/s samples in this launch                       */
+    int n_slots;               /* n_streams * 2                                        */
+    const uint8_t *slot_active;
+    double *state_d; float *state_f; int *state_i;
+    uint8_t *bits; int bits_cap; int *nbits;
+    double *dphi;              /* optional debug tap, same layout as y3 (or NULL)      */
+} nvx_demod_args;
+
+typedef struct {
+    const nvx_synth_desc *desc;
+    const nvx_period *pool;
+    uint32_t *out; size_t pitch; size_t n; uint32_t spb;
+} nvx_synth_args;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s);
+hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s);
+hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s);
+double nvx_atan2_host(double y, double x);
+#ifdef __cplusplus
+}
+#endif
+#endif

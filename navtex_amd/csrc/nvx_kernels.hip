@@ -1,0 +1,535 @@
+// nvx_kernels.hip -- gfx950 kernels of the NAVTEX receive path.
+//
+//   nvx_fir_cascade<RAW, NCH>   int16 IQ in HBM -> 900 S/s complex fp64 per chain
+//        stage 0 (/8 integer, build-owned, RAW only)
+//        FIR1 37 taps /4        receiver/fir1cpp.C:80-136
+//        mixer +-14 kHz         receiver/fir2cpp.C:112-128
+//        FIR2 47 taps /7        receiver/fir2cpp.C:131-215
+//        FIR3 71 taps /10       receiver/fir3cpp.C:22-60
+//   nvx_demod                   900 S/s -> 'B'/'Y' bits
+//        discriminator          receiver/decoder.C:42-59
+//        bit-timing filter      receiver/decoder.C:142-255
+//        mark/space decision    receiver/decoder.C:73-137
+//   nvx_synth_kernel            deterministic CPFSK test source (no reference counterpart)
+//
+// Arithmetic contract (what makes results bit-identical to the reference's
+// x86-64 build): every FIR output is accumulated by ONE lane, acc = 0.0 then
+// acc = acc + h[i]*x in tap order, product and sum rounded separately (this
+// file is compiled with -ffp-contract=off; check the ISA for v_fma_f64: there
+// must be none outside nvx_atan2), I and Q independently, fp64 throughout.
+//
+// Design of the cascade kernel (HBM-read bound; no MFMA -- 1-D decimating
+// convolutions):
+//   * one 64-lane wavefront per IQ stream walks that stream through time, so
+//     every input byte is read from HBM exactly once and no halo is re-read;
+//     filter histories live in LDS between passes and in HBM between launches;
+//   * a pass = 64 FIR1 outputs = 256 samples @252 kS/s = 2048 raw samples =
+//     8 KiB: eight fully coalesced 1-KiB global_load_dwordx4 per wave, issued
+//     one pass ahead into registers (prefetch) so HBM latency hides behind the
+//     fp64 work of the current pass;
+//   * stage 0 sums 8 raw samples with v_dot2c_i32_i16 (sign-extend + add in
+//     one op) and one DPP lane-pair exchange; each lane converts one component
+//     to fp64 and writes it to the LDS window;
+//   * the 252 kS/s window is kept polyphase-split (4 arrays of {I,Q} doubles)
+//     so that lane k's tap reads are consecutive 16-byte words: every
+//     ds_read_b128 / ds_write_b64 below is bank-conflict free;
+//   * FIR2 runs when 224 mixer outputs are buffered (32 outputs x {I,Q} = 64
+//     lanes), FIR3 when 160 FIR2 outputs are buffered (16 outputs x {I,Q});
+//   * a launch covers whole frames of 32 bit periods = 315 passes = 90 FIR2
+//     runs = 18 FIR3 runs, after which every decimation counter, the mixer
+//     index and all LDS fill levels are back at zero: the carried state is
+//     just the three filter histories.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nvx_tables.h"
+#include "nvx_atan2.h"
+#include "nvx_synth.h"
+#include "nvx_kernels.h"
+
+// A single wave owns all LDS it touches; LDS instructions of one wave execute
+// in program order, so cross-lane hand-offs need no s_barrier and no waitcnt --
+// only the compiler must be kept from reordering the accesses.
+#define NVX_WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+typedef short nvx_short2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal builtin needs it
+
+// ------------------------------------------------------------------ LDS map
+// X: four polyphase arrays of 74 double2 (9 history + 64 new + 1 pad; the pad
+//    makes the array stride = 8 banks mod 32 so the stage-0 writes spread)
+// U[c]:  mixer output buffer, 46 history + up to 224+63 pending  (336 double2)
+// Y2[c]: FIR2 output buffer, 70 history + up to 160+31 pending  (264 double2)
+// MIX:   9 + 9 doubles
+#define XS 74
+#define X_ENTRIES (4 * XS)
+#define U_ENTRIES 336
+#define Y2_ENTRIES 264
+#define U_RUN 224
+#define Y2_RUN 160
+
+template <int NCH>
+struct CascadeLds {
+    double2 X[X_ENTRIES];
+    double2 U[NCH][U_ENTRIES];
+    double2 Y2[NCH][Y2_ENTRIES];
+    double  mix[2 * NVX_MIX_N];
+};
+
+// NB: __builtin_bit_cast applied directly to a vector-element expression (v.x)
+// reads element 0 for every component with this compiler; go through a by-value
+// scalar instead.
+__device__ __forceinline__ nvx_short2 as_short2(unsigned w) { return __builtin_bit_cast(nvx_short2, w); }
+
+__device__ __forceinline__ int dpp_swap_pairs(int v)
+{
+    // quad_perm [1,0,3,2]: every lane reads its lane^1 neighbour
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+}
+
+// stage 0 for one 1-KiB load: lane l holds raw samples 4l..4l+3 of the KiB;
+// lanes (2i, 2i+1) together hold the 8 samples of output i.  Even lanes end
+// up with the I sum, odd lanes with the Q sum, already rounded and shifted.
+__device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
+{
+    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };
+    int sI = 2, sQ = 2;                       // 2 + 2 = the +4 of round-half-up
+    sI = __builtin_amdgcn_sdot2(as_short2(v.x), selI, sI, false);
+    sQ = __builtin_amdgcn_sdot2(as_short2(v.x), selQ, sQ, false);
+    sI = __builtin_amdgcn_sdot2(as_short2(v.y), selI, sI, false);
+    sQ = __builtin_amdgcn_sdot2(as_short2(v.y), selQ, sQ, false);
+    sI = __builtin_amdgcn_sdot2(as_short2(v.z), selI, sI, false);
+    sQ = __builtin_amdgcn_sdot2(as_short2(v.z), selQ, sQ, false);
+    sI = __builtin_amdgcn_sdot2(as_short2(v.w), selI, sI, false);
+    sQ = __builtin_amdgcn_sdot2(as_short2(v.w), selQ, sQ, false);
+    int keep = odd ? sQ : sI;
+    int give = odd ? sI : sQ;
+    int tot = keep + dpp_swap_pairs(give);
+    return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
+}
+
+template <bool RAW>
+__device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 *src)
+{
+    // src already points at this lane's first 16 bytes of the pass
+    if (RAW) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) pf[j] = __builtin_nontemporal_load(src + 64 * j);
+    } else {
+        pf[0] = __builtin_nontemporal_load(src);
+    }
+}
+
+template <bool RAW, int NCH>
+__global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
+{
+    __shared__ CascadeLds<NCH> lds;
+    const int lane = threadIdx.x;
+    const int stream = blockIdx.x;
+    if (stream >= a.n_streams) return;
+
+    const unsigned mask = a.chain_masks[stream];
+    // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
+    const int chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
+
+    // ---------------------------------------------------------- state in
+    double2 *st = (double2 *)(a.state + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+    if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
+        int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
+        lds.X[r * XS + e] = st[lane];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int ch = (NCH == 1) ? chain_of_slot0 : c;
+        const double2 *su = st + 36 + ch * (46 + 70);
+        if (lane < 46) lds.U[c][lane] = su[lane];
+        lds.Y2[c][lane] = su[46 + lane];
+        if (lane < 6) lds.Y2[c][64 + lane] = su[46 + 64 + lane];
+    }
+    if (lane < NVX_MIX_N) {
+        // constant-index selects keep the tables out of scratch
+        double cr = 0.0, ci = 0.0;
+#pragma unroll
+        for (int j = 0; j < NVX_MIX_N; j++) if (lane == j) { cr = NVX_MIX_CR[j]; ci = NVX_MIX_CI[j]; }
+        lds.mix[lane] = cr; lds.mix[NVX_MIX_N + lane] = ci;
+    }
+    NVX_WAVE_LDS_FENCE();
+
+    // ---------------------------------------------------------- addressing
+    const size_t pass_words = RAW ? 2048 : 256;    // 32-bit IQ words per pass
+    const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + lane;
+    const int total_passes = a.n_frames * NVX_PASSES_PER_FRAME;
+
+    // stage-0 write slot of this lane (RAW): output m = 32j + (lane>>1):
+    // phase r = m & 3, index k' = m >> 2 = 8j + (lane>>3), component = lane & 1
+    double *xw = (double *)&lds.X[((lane >> 1) & 3) * XS + 9 + (lane >> 3)] + (lane & 1);
+    const bool odd = lane & 1;
+    // FIR1 read base of this lane: X[r*XS + 9 + lane - q]
+    const double2 *xr = &lds.X[9 + lane];
+    // FIR2 / FIR3: lane = 2*output + component
+    const int half = lane >> 1, comp = lane & 1;
+    int lane_mod9 = lane % 9;
+
+    u32x4 pf[RAW ? 8 : 1];
+    load_pass<RAW>(pf, src);
+
+    int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = 0;
+
+    for (int pass = 0; pass < total_passes; pass++) {
+        // ---- 1. new 252 kS/s samples into the polyphase window ----------
+        if (RAW) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], odd);       // +8 double2 entries per load
+        } else {
+            // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
+            const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double2 v;
+                v.x = (double)(int)(short)(w[r] & 0xffffu);       // capt_sched.c:511 (double) of each short
+                v.y = (double)((int)w[r] >> 16);
+                lds.X[r * XS + 9 + lane] = v;
+            }
+        }
+        // ---- 2. prefetch the next pass ------------------------------------
+        src += pass_words / 4;
+        if (pass + 1 < total_passes) load_pass<RAW>(pf, src);
+        NVX_WAVE_LDS_FENCE();
+
+        // ---- 3. FIR1: y1[k] = sum_i h1[i] * x[4k+3-i] ----------------------
+        double aI = 0.0, aQ = 0.0;
+#pragma unroll
+        for (int i = 0; i < NVX_T1; i++) {
+            const int q = i >> 2, r = 3 - (i & 3);
+            double2 x = xr[r * XS - q];
+            aI += NVX_H1[i] * x.x;
+            aQ += NVX_H1[i] * x.y;
+        }
+        // ---- 4. mixer, table index (k mod 9), k counted from stream start --
+        int j9 = mixbase + lane_mod9; if (j9 >= NVX_MIX_N) j9 -= NVX_MIX_N;
+        const double cr = lds.mix[j9], ci = lds.mix[NVX_MIX_N + j9];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int ch = (NCH == 1) ? chain_of_slot0 : c;
+            double2 u;
+            if (ch == 0) {                 // 518 chain, fir2cpp.C:116-117
+                u.x = aI * cr - aQ * ci;
+                u.y = aI * ci + aQ * cr;
+            } else {                       // 490 chain, fir2cpp.C:122-123
+                u.x = aI * cr + aQ * ci;
+                u.y = -aI * ci + aQ * cr;
+            }
+            lds.U[c][46 + n_u + lane] = u;
+        }
+        n_u += 64;
+        mixbase += 1; if (mixbase == NVX_MIX_N) mixbase = 0;      // 64 mod 9 == 1
+        // ---- 5. slide the 9-deep history of each phase to the front --------
+        NVX_WAVE_LDS_FENCE();
+        if (lane < 36) {
+            int e = lane >> 2, r = lane & 3;
+            double2 t = lds.X[r * XS + 64 + e];
+            lds.X[r * XS + e] = t;
+        }
+        NVX_WAVE_LDS_FENCE();
+
+        // ---- 6. FIR2 when 224 mixer outputs are pending ---------------------
+        while (n_u >= U_RUN) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (NCH == 2 && !((mask >> c) & 1u)) continue;
+                const double *ub = (const double *)&lds.U[c][7 * half] + comp;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < NVX_T2; i++) acc += NVX_H2[i] * ub[2 * (52 - i)];
+                ((double *)&lds.Y2[c][70 + n_y2 + half])[comp] = acc;
+            }
+            NVX_WAVE_LDS_FENCE();
+            // drop the 224 consumed inputs: keep 46 history + pending
+            const int keep = 46 + n_u - U_RUN;                  // <= 109
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                double2 t0 = lds.U[c][U_RUN + lane];
+                double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 48) ? lane : 47)];
+                NVX_WAVE_LDS_FENCE();
+                if (lane < keep) lds.U[c][lane] = t0;
+                if (lane + 64 < keep) lds.U[c][64 + lane] = t1;
+            }
+            NVX_WAVE_LDS_FENCE();
+            n_u -= U_RUN;
+            n_y2 += 32;
+
+            // ---- 7. FIR3 when 160 FIR2 outputs are pending ------------------
+            if (n_y2 >= Y2_RUN) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    if (NCH == 2 && !((mask >> c) & 1u)) continue;
+                    const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                    const int p = half & 15;
+                    const double *yb = (const double *)&lds.Y2[c][10 * p] + comp;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
+                    if (lane < 32) {
+                        double *out = (double *)(a.y3 + ((size_t)(stream * 2 + ch) * a.y3_cap + a.y3_base + n3_done + p));
+                        out[comp] = acc;
+                    }
+                }
+                NVX_WAVE_LDS_FENCE();
+                const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    double2 t0 = lds.Y2[c][Y2_RUN + lane];
+                    double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 40) ? lane : 39)];
+                    NVX_WAVE_LDS_FENCE();
+                    if (lane < keep3) lds.Y2[c][lane] = t0;
+                    if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
+                }
+                NVX_WAVE_LDS_FENCE();
+                n_y2 -= Y2_RUN;
+                n3_done += 16;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------- state out
+    NVX_WAVE_LDS_FENCE();
+    if (lane < 36) {
+        int e = lane >> 2, r = lane & 3;
+        st[lane] = lds.X[r * XS + e];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int ch = (NCH == 1) ? chain_of_slot0 : c;
+        double2 *su = st + 36 + ch * (46 + 70);
+        if (lane < 46) su[lane] = lds.U[c][lane];
+        su[46 + lane] = lds.Y2[c][lane];
+        if (lane < 6) su[46 + 64 + lane] = lds.Y2[c][64 + lane];
+    }
+}
+
+// ===========================================================================
+// demodulator: one lane per chain, sequential over the block's 900 S/s samples
+// ===========================================================================
+// State layout (struct-of-arrays over chains, nc = number of chain slots):
+//   doubles: prevI, prevQ, dab[9], csa[9], cb[567]      -> field f at d[f*nc + chain]
+//   floats : BR, BI, YR, YI
+//   ints   : see enum below
+enum { DI_BS_SEQ = 0, DI_STATUS, DI_SAMPLECOUNT, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_BURN,
+       DI_DAB_INDEX, DI_CB_INDEX, DI_CSA_INDEX, DI_DAB_PRIMED, DI_CB_PRIMED, DI_CSA_PRIMED,
+       DI_PREV_OFFSET, DI_BD_SEQ, DI_COUNT };
+enum { DD_PREVI = 0, DD_PREVQ = 1, DD_DAB = 2, DD_CSA = 11, DD_CB = 20, DD_COUNT = 20 + 567 };
+static_assert(DI_COUNT == NVX_DEMOD_INTS && DD_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET, "state layout");
+
+enum { ST_INIT = 0, ST_WAIT = 1, ST_BIT_START = 2, ST_RECEIVING = 3 };   // decoder.h:16-19
+
+__global__ __launch_bounds__(64) void nvx_demod(nvx_demod_args a)
+{
+    __shared__ double s_dab[9][64];
+    __shared__ double s_csa[9][64];
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x * 64 + tid;
+    const int nc = a.n_slots;
+    if (slot >= nc) return;
+    if (!a.slot_active[slot]) return;
+
+    double *sd = a.state_d;
+    float  *sf = a.state_f;
+    int    *si = a.state_i;
+#define SD(f) sd[(size_t)(f) * nc + slot]
+#define SF(f) sf[(size_t)(f) * nc + slot]
+#define SI(f) si[(size_t)(f) * nc + slot]
+
+    double prevI = SD(DD_PREVI), prevQ = SD(DD_PREVQ);
+    for (int i = 0; i < 9; i++) { s_dab[i][tid] = SD(DD_DAB + i); s_csa[i][tid] = SD(DD_CSA + i); }
+    float BR = SF(0), BI = SF(1), YR = SF(2), YI = SF(3);
+    int bs_seq = SI(DI_BS_SEQ), status = SI(DI_STATUS), samplecount = SI(DI_SAMPLECOUNT);
+    int sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF), burn = SI(DI_BURN);
+    int dab_index = SI(DI_DAB_INDEX), cb_index = SI(DI_CB_INDEX), csa_index = SI(DI_CSA_INDEX);
+    int dab_primed = SI(DI_DAB_PRIMED), cb_primed = SI(DI_CB_PRIMED), csa_primed = SI(DI_CSA_PRIMED);
+    int prev_offset = SI(DI_PREV_OFFSET), bd_seq = SI(DI_BD_SEQ);
+
+    const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
+    uint8_t *bits = a.bits + (size_t)slot * a.bits_cap;
+    double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
+    int nbits = 0;
+
+    for (int t = 0; t < a.n3; t++) {
+        const double2 s = y3[t];
+        // ---- discriminator, decoder.C:48-55
+        const double prodReal = s.x * prevI + s.y * prevQ;
+        const double prodImg  = s.y * prevI - s.x * prevQ;
+        const double ds = nvx_atan2(prodImg, prodReal);
+        prevI = s.x; prevQ = s.y;
+        if (dphi_out) dphi_out[t] = ds;
+
+        // ---- bit-timing filter, decoder.C:142-255
+        s_dab[dab_index][tid] = ds;
+        if (++dab_index == 9) { dab_index = 0; dab_primed = 1; }
+        if (dab_primed) {
+            double temp = 0.0;
+            int j = dab_index;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                temp += (double)NVX_CORR_MASK[i] * s_dab[j][tid];
+                if (++j == 9) j = 0;
+            }
+            SD(DD_CB + cb_index) = __builtin_fabs(temp);
+            if (++cb_index == 567) { cb_index = 0; cb_primed = 1; }
+        }
+        if (cb_primed) {
+            double temp = 0.0;
+            for (int i = csa_index; i < 567; i += 9) temp += SD(DD_CB + i);
+            s_csa[csa_index][tid] = temp;
+            if (++csa_index == 9) { csa_index = 0; csa_primed = 1; }
+        }
+        if (csa_primed) {
+            if (bs_seq == 0) {
+                double temp_max = -1.0;
+                int max_index = 0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double v = s_csa[i][tid];
+                    if (v > temp_max) { temp_max = v; max_index = i; }
+                }
+                if (!(prev_offset == -1 || max_index == prev_offset)) {
+                    if (max_index > prev_offset) {
+                        if (max_index - prev_offset > 4) max_index = (prev_offset - 1 + 9) % 9;
+                        else                             max_index = (prev_offset + 1) % 9;
+                    } else {
+                        if (prev_offset - max_index > 4) max_index = (prev_offset + 1) % 9;
+                        else                             max_index = (prev_offset - 1 + 9) % 9;
+                    }
+                }
+                prev_offset = max_index;
+                const int offset = (max_index + 5) % 9;          // decoder.C:249
+                if (status == ST_INIT) { status = ST_WAIT; sync_off = offset; }   // decoder.C:62-70
+                next_sync_off = offset;
+            }
+            if (++bs_seq == 9) bs_seq = 0;
+        }
+
+        // ---- mark/space decision, decoder.C:73-137 (bd_seq kept modulo 9)
+        if (++bd_seq == 9) bd_seq = 0;
+        if (status == ST_INIT) continue;
+        if (status == ST_WAIT && bd_seq == sync_off) { status = ST_BIT_START; burn = 0; }
+        if (status == ST_BIT_START) {
+            if (burn == 2) {
+                status = ST_RECEIVING; samplecount = 0;
+                BR = 0.0f; BI = 0.0f; YR = 0.0f; YI = 0.0f;
+            } else {
+                burn++;
+            }
+            continue;
+        }
+        if (status == ST_RECEIVING) {
+            float fR = 0.0f, fI = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (samplecount == i) { fR = NVX_BF_R[i]; fI = NVX_BF_I[i]; }
+            const double sampleR = s.x, sampleI = s.y;
+            // decoder.C:115-118: float*float product, double*float product,
+            // double sum, accumulate in double, round to float
+            YR = (float)((double)YR + ((double)((float)sampleR * fR) - sampleI * (double)fI));
+            YI = (float)((double)YI + ((double)((float)sampleR * fI) + sampleI * (double)fR));
+            BR = (float)((double)BR + ((double)((float)sampleR * fR) + sampleI * (double)fI));
+            BI = (float)((double)BI + ((double)((float)(-sampleR) * fI) + sampleI * (double)fR));
+            if (++samplecount == 5) {
+                const float Brot = BR * BR + BI * BI;
+                const float Yrot = YR * YR + YI * YI;
+                if (nbits < a.bits_cap) bits[nbits] = (Brot > Yrot) ? 'B' : 'Y';
+                nbits++;
+                status = ST_WAIT;
+                sync_off = next_sync_off;
+            }
+        }
+    }
+
+    a.nbits[slot] = nbits;
+    SD(DD_PREVI) = prevI; SD(DD_PREVQ) = prevQ;
+    for (int i = 0; i < 9; i++) { SD(DD_DAB + i) = s_dab[i][tid]; SD(DD_CSA + i) = s_csa[i][tid]; }
+    SF(0) = BR; SF(1) = BI; SF(2) = YR; SF(3) = YI;
+    SI(DI_BS_SEQ) = bs_seq; SI(DI_STATUS) = status; SI(DI_SAMPLECOUNT) = samplecount;
+    SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off; SI(DI_BURN) = burn;
+    SI(DI_DAB_INDEX) = dab_index; SI(DI_CB_INDEX) = cb_index; SI(DI_CSA_INDEX) = csa_index;
+    SI(DI_DAB_PRIMED) = dab_primed; SI(DI_CB_PRIMED) = cb_primed; SI(DI_CSA_PRIMED) = csa_primed;
+    SI(DI_PREV_OFFSET) = prev_offset; SI(DI_BD_SEQ) = bd_seq;
+#undef SD
+#undef SF
+#undef SI
+}
+
+// ===========================================================================
+// synthetic source
+// ===========================================================================
+__global__ __launch_bounds__(256) void nvx_synth_kernel(nvx_synth_args a)
+{
+    const int stream = blockIdx.y;
+    const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // 4 samples per thread
+    const size_t n0 = quad * 4;
+    if (n0 >= a.n) return;
+    const nvx_synth_desc d = a.desc[stream];
+    uint32_t ph[2] = { 0, 0 }, inc[2] = { 0, 0 }, r[2] = { 0, 0 };
+    size_t b[2] = { 0, 0 };
+    for (int c = 0; c < d.n_carriers; c++) {
+        const uint64_t g = (uint64_t)n0 + d.bit_offset[c];
+        b[c] = (size_t)(g / a.spb);
+        r[c] = (uint32_t)(g - (uint64_t)b[c] * a.spb);
+        const nvx_period p = a.pool[d.pool_off[c] + b[c]];
+        inc[c] = p.inc; ph[c] = p.phase + r[c] * p.inc;
+    }
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int32_t I = 0, Q = 0;
+        for (int c = 0; c < d.n_carriers; c++) {
+            nvx_synth_tone(ph[c], d.amp[c], &I, &Q);
+            ph[c] += inc[c];
+            if (++r[c] == a.spb) {                 // next bit period
+                r[c] = 0; b[c]++;
+                const nvx_period p = a.pool[d.pool_off[c] + b[c]];
+                inc[c] = p.inc; ph[c] = p.phase;
+            }
+        }
+        if (d.noise_amp > 0) nvx_synth_noise(d.seed, (uint64_t)(n0 + k), d.noise_amp, &I, &Q);
+        w[k] = nvx_synth_pack(I, Q);
+    }
+    uint32_t *out = a.out + (size_t)stream * a.pitch + n0;
+    if (n0 + 4 <= a.n) {
+        *(uint4 *)out = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (size_t k = 0; n0 + k < a.n; k++) out[k] = w[k];
+    }
+}
+
+// ===========================================================================
+// launchers (C linkage, called from nvx_api.cpp)
+// ===========================================================================
+extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s)
+{
+    dim3 grid((unsigned)a->n_streams), block(64);
+    if (raw) {
+        if (nch == 1) hipLaunchKernelGGL((nvx_fir_cascade<true, 1>), grid, block, 0, s, *a);
+        else          hipLaunchKernelGGL((nvx_fir_cascade<true, 2>), grid, block, 0, s, *a);
+    } else {
+        if (nch == 1) hipLaunchKernelGGL((nvx_fir_cascade<false, 1>), grid, block, 0, s, *a);
+        else          hipLaunchKernelGGL((nvx_fir_cascade<false, 2>), grid, block, 0, s, *a);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s)
+{
+    dim3 grid((unsigned)((a->n_slots + 63) / 64)), block(64);
+    hipLaunchKernelGGL(nvx_demod, grid, block, 0, s, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s)
+{
+    const size_t quads = (a->n + 3) / 4;
+    dim3 grid((unsigned)((quads + 255) / 256), (unsigned)n_streams), block(256);
+    hipLaunchKernelGGL(nvx_synth_kernel, grid, block, 0, s, *a);
+    return hipGetLastError();
+}
+
+// host-callable copy of the device atan2, for tests (tests/test_atan2.py)
+extern "C" __attribute__((visibility("default"))) double nvx_atan2_host(double y, double x) { return nvx_atan2(y, x); }
