@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the NAVTEX hot path on MI355X.
+
+Workload (BASELINE.json configs[3], the "HBM roofline run"; configs[4] is the
+same per GPU): 4096 independent synthetic 170 Hz-shift FSK channels per GPU,
+each an int16 IQ stream at 2.016 MS/s resident in HBM, run through
+stage 0 (/8) -> FIR1 -> mixer -> FIR2 -> FIR3 -> FSK discriminator -> bit sync
+-> mark/space decision -> host SITOR-B character layer.
+
+One "step" = one pass of that path over the whole resident batch
+(streams x frames x 645120 samples).  Multi-GPU: one process per GPU
+(torch.distributed / RCCL only for the barrier and the max-over-ranks of the
+elapsed time); streams shard one subset per GPU, no data-path collective,
+weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+BYTES_PER_SAMPLE = 4           # int16 I + int16 Q, each read from HBM exactly once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=4096, help="IQ streams per GPU")
+    ap.add_argument("--frames", type=int, default=12, help="frames (0.32 s each) resident per stream")
+    ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-charlayer", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import navtex_amd as nv
+    import signals
+
+    if nv.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
+    device = local
+    S, F = args.streams, args.frames
+    pitch = F * nv.FRAME_RAW
+    samples_per_step = S * pitch
+    bytes_per_step = samples_per_step * BYTES_PER_SAMPLE
+
+    # ---- synthetic input, generated on the device, resident in HBM ----------
+    t0 = time.time()
+    streams = []
+    for s in range(S):
+        gid = rank * S + s                                     # global stream id: subsets per GPU
+        st, _ = signals.stream_params(nv, gid, nv.RATE_RAW)
+        streams.append(st)
+    buf = nv.DeviceBuffer(bytes_per_step, device=device)
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    t_gen = time.time() - t0
+
+    pipe = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F,
+                       char_layer=not args.no_charlayer, device=device)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    # ---- parity gate + CPU baseline (rank 0, N = 1 leg of the contract) ------
+    cpu = None
+    parity = None
+    if rank == 0:
+        import oracle_binding as ob
+        # the GPU box gives one GPU a 16-thread CPU share whatever the affinity mask says
+        ncpu = int(os.environ.get("NVX_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
+        n_cs = min(args.cpu_streams or 2 * ncpu, S)
+        cf = min(F, 4)                 # the first bit needs ~66 bit periods; 4 frames = 128
+        # the sample = the first cf frames of the first n_cs streams, copied back from HBM
+        sample = np.empty((n_cs, cf * nv.FRAME_RAW, 2), dtype=np.int16)
+        for s in range(n_cs):
+            sample[s] = buf.download(cf * nv.FRAME_RAW * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+        # GPU bits for the same frames, from reset state
+        pipe.process_resident(buf, pitch, 0, cf)
+        pipe.fetch()
+        gpu_bits = [pipe.bits(s, 0) for s in range(n_cs)]
+        if not args.no_cpu and world == 1:
+            n252 = cf * nv.FRAME_IN
+            per_pass = n_cs * cf * nv.FRAME_RAW
+            # calibrate, then size the repeat count for ~6 s wall on all threads (~100 core-seconds
+            # at 16 threads would exceed the "few minutes" budget; this is ~6 s x ncpu core-seconds)
+            sN, cpu_bits = ob.bench(sample, n_cs, n252, True, 1, ncpu, want_bits=True)
+            rep = max(1, int(6.0 / max(sN, 1e-3)))
+            sN = ob.bench(sample, n_cs, n252, True, 1, ncpu, repeat=rep)[0]
+            one = min(n_cs, 2)
+            s1 = ob.bench(sample[:one], one, n252, True, 1, 1, repeat=max(1, rep // 8))[0]
+            cpu = {
+                "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
+                "cores": ncpu, "kind": "port",
+                "value_1thread": round(one * cf * nv.FRAME_RAW * max(1, rep // 8) / s1 / 1e6, 2),
+                "sample": f"first {cf} frames of the first {n_cs} streams of the bench batch ({per_pass / 1e6:.0f} M raw samples), "
+                          f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
+                "seconds": round(sN, 2),
+            }
+        else:
+            cpu_bits = []
+            for s in range(n_cs if world == 1 else min(n_cs, 4)):
+                o = ob.Pipe(chain_mask=1, charlayer=False)
+                o.push_raw(sample[s])
+                cpu_bits.append(o.bits(0))
+        parity = all(g == c for g, c in zip(gpu_bits, cpu_bits)) and len(cpu_bits) > 0 and all(len(c) > 0 for c in cpu_bits)
+        if not parity:
+            print("PARITY FAILURE: GPU bits differ from the CPU oracle", file=sys.stderr)
+    pipe.reset()
+
+    # ---- warm-up, then EXACTLY K timed steps ------------------------------------
+    def step():
+        pipe.process_resident(buf, pitch, 0, F)
+
+    for _ in range(args.warmup):
+        step()
+    pipe.fetch()
+    pipe.enable_timing(True)
+    pipe.kernel_time_stats(0, reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    pipe.fetch()                       # all launches done, bits on the host, characters decoded
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    casc_ms, n_l = pipe.kernel_time_stats(0)
+    dem_ms, _ = pipe.kernel_time_stats(1)
+    total_bits = sum(pipe.bit_count(s, 0) for s in range(0, S, max(1, S // 64)))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * samples_per_step * args.steps / elapsed / 1e6
+        casc_avg = casc_ms / max(n_l, 1)
+        achieved = bytes_per_step / (casc_avg * 1e-3) / 1e9 if casc_avg > 0 else None
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text())
+                if rec.get("streams") == S and rec.get("frames") == F:
+                    traffic = rec.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(value, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, "
+                                   f"{F} frames ({F * 0.32:.2f} s) resident in HBM (BASELINE configs[3]; x{world} GPUs = configs[4] shape)",
+                       "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step,
+                       "stage0": "integrate-and-dump /8 (build-owned)", "chains_per_stream": 1,
+                       "parallelism": f"streams sharded {world} ways, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>", "achieved": round(achieved, 1) if achieved else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_step,
+                         "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),
+                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3)},
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "hbm_gbs_whole_job": round(world * bytes_per_step * args.steps / elapsed / 1e9, 1),
+            "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
+        }
+        print(json.dumps(line), flush=True)
+
+    pipe.close()
+    buf.free()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

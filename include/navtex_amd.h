@@ -151,6 +151,9 @@ NVX_API size_t nvx_bit_count(nvx_handle *h, int stream, int chain);
  * which = 0 FIR cascade, 1 demodulator.  Valid after a synchronise.          */
 NVX_API float nvx_last_kernel_ms(nvx_handle *h, int which);
 NVX_API void  nvx_enable_timing(nvx_handle *h, int enabled);
+/* sum of the event durations (ms) and number of timed launches collected since
+ * the last reset of the statistics; reset != 0 clears them afterwards          */
+NVX_API int   nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, uint64_t *launches, int reset);
 /* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */
 NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
 /* debug tap: copy the 900 S/s FIR-cascade output of the LAST launch for one

@@ -203,6 +203,12 @@ class Pipeline:
     def kernel_ms(self, which: int) -> float:
         return float(lib.nvx_last_kernel_ms(self._h, which))
 
+    def kernel_time_stats(self, which: int, reset: bool = False):
+        """(sum of HIP-event ms, number of launches) for kernel `which` (0 cascade, 1 demod)."""
+        s, n = C.c_double(), C.c_uint64()
+        N.check(lib.nvx_kernel_time_stats(self._h, which, C.byref(s), C.byref(n), int(reset)), "nvx_kernel_time_stats")
+        return s.value, n.value
+
     def debug_y3(self, stream: int = 0, chain: int = 0) -> np.ndarray:
         out = np.empty((self.max_frames * FRAME_Y3, 2), dtype=np.float64)
         n = lib.nvx_debug_y3(self._h, stream, chain, N.as_ptr(out), out.shape[0])

@@ -44,7 +44,7 @@ class SynthStream(C.Structure):
 def _load() -> C.CDLL:
     if not _LIB_PATH.exists():
         raise ImportError(
-            f"{_LIB_PATH} is missing: build it with `python -m navtex_amd.build` "
+            f"{_LIB_PATH} is missing: build it with `python navtex_amd/build.py` "
             "(hipcc, gfx950). navtex_amd has no pure-Python or CPU fallback.")
     lib = C.CDLL(str(_LIB_PATH))
     vp, sz, i, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
@@ -60,6 +60,7 @@ def _load() -> C.CDLL:
         "nvx_process_resident": (i, [vp, vp, sz, sz, i, vp]), "nvx_fetch_bits": (i, [vp]),
         "nvx_bit_count": (sz, [vp, i, i]),
         "nvx_last_kernel_ms": (C.c_float, [vp, i]), "nvx_enable_timing": (None, [vp, i]), "nvx_enable_debug": (i, [vp, i]),
+        "nvx_kernel_time_stats": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]),
         "nvx_debug_y3": (sz, [vp, i, i, vp, sz]), "nvx_debug_dphi": (sz, [vp, i, i, vp, sz]),
         "nvx_device_count": (i, []), "nvx_device_alloc": (vp, [i, sz]), "nvx_device_free": (None, [i, vp]),
         "nvx_memcpy_h2d": (i, [i, vp, vp, sz]), "nvx_memcpy_d2h": (i, [i, vp, vp, sz]), "nvx_device_sync": (i, [i]),

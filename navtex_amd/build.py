@@ -2,8 +2,11 @@
 in-tree with hipcc, and -- for tests only -- the oracle library and the compiled
 reference seams via oracle/Makefile.
 
-    python -m navtex_amd.build            # product library
-    python -m navtex_amd.build --oracle   # + oracle (and reference seams when /root/reference exists)
+    python navtex_amd/build.py            # product library
+    python navtex_amd/build.py --oracle   # + oracle (and reference seams when /root/reference exists)
+
+Run it as a script (or load it by path): importing the navtex_amd package itself
+requires the library to exist already.
 """
 from __future__ import annotations
 

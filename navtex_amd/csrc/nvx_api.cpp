@@ -70,6 +70,8 @@ struct Result {                        // one in-flight launch's bit output
     uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
     uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };   // before cascade / between / after demod
+    bool timed = false;
     bool pending = false;
 };
 
@@ -83,14 +85,16 @@ struct nvx_handle {
     uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
     double2 *d_y3 = nullptr;
     double *d_dd = nullptr, *d_dphi = nullptr; float *d_df = nullptr; int *d_di = nullptr;
+    signed char *d_argmax = nullptr;
+    unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
     Result res[RESULT_SLOTS];
     uint64_t launched = 0, collected = 0;
     int last_n3 = 0;
     // timing
     bool timing = false;
-    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };
-    float ms[2] = { 0.f, 0.f };
-    bool ev_valid = false;
+    float ms[2] = { 0.f, 0.f };          // last collected launch
+    double ms_sum[2] = { 0.0, 0.0 };     // over all collected launches since the last stats reset
+    uint64_t ms_count = 0;
     // host
     std::vector<uint8_t> masks;
     std::vector<Slot> slots;
@@ -135,14 +139,14 @@ static void free_handle(nvx_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3);
-    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in);
+    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_argmax);
     for (auto &r : h->res) {
         hipFree(r.d_bits); hipFree(r.d_nbits);
         if (r.h_bits) hipHostFree(r.h_bits);
         if (r.h_nbits) hipHostFree(r.h_nbits);
         if (r.done) hipEventDestroy(r.done);
+        for (int i = 0; i < 3; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
     }
-    for (int i = 0; i < 3; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
         if (h->stage_free[i]) hipEventDestroy(h->stage_free[i]);
@@ -209,14 +213,15 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_df, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
+    CR_TRY(hipMalloc(&h->d_argmax, (size_t)(h->y3_cap / 9) * h->n_slots));
     for (auto &r : h->res) {
         CR_TRY(hipMalloc(&r.d_bits, (size_t)h->n_slots * h->bits_cap));
         CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
         CR_TRY(hipHostMalloc((void **)&r.h_bits, (size_t)h->n_slots * h->bits_cap, hipHostMallocDefault));
         CR_TRY(hipHostMalloc((void **)&r.h_nbits, (size_t)h->n_slots * sizeof(int), hipHostMallocDefault));
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
-    for (int i = 0; i < 3; i++) CR_TRY(hipEventCreate(&h->ev[i]));
     if (cfg->push_mode) {
         h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
         for (int i = 0; i < 2; i++) {
@@ -243,6 +248,7 @@ extern "C" int nvx_reset(nvx_handle *h)
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto &r : h->res) r.pending = false;
     h->collected = h->launched;
+    h->g0 = 0;
     HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_df, 0, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float), h->stream));
@@ -271,20 +277,22 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     nvx_demod_args da{};
     da.y3 = h->d_y3; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
-    da.state_d = h->d_dd; da.state_f = h->d_df; da.state_i = h->d_di;
+    da.g0 = h->g0; da.dstate = h->d_dd; da.state_f = h->d_df; da.state_i = h->d_di; da.argmax = h->d_argmax;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
 
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], st));
+    r.timed = h->timing;
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[0], st));
     HIP_TRY(nvx_launch_cascade(&ca, h->cfg.raw_rate, h->nch, st));
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], st));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
     HIP_TRY(nvx_launch_demod(&da, st));
-    if (h->timing) { HIP_TRY(hipEventRecord(h->ev[2], st)); h->ev_valid = true; }
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], st));
     HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(r.done, st));
     r.pending = true;
     h->launched++;
     h->last_n3 = da.n3;
+    h->g0 += (unsigned long long)da.n3;
     return NVX_OK;
 }
 
@@ -295,6 +303,11 @@ static int collect_locked(nvx_handle *h)
         Result &r = h->res[h->collected % RESULT_SLOTS];
         if (r.pending) {
             HIP_TRY(hipEventSynchronize(r.done));
+            if (r.timed) {
+                HIP_TRY(hipEventElapsedTime(&h->ms[0], r.ev[0], r.ev[1]));
+                HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[1], r.ev[2]));
+                h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
+            }
             for (int i = 0; i < h->n_slots; i++) {
                 Slot &s = h->slots[i];
                 if (!s.active) continue;
@@ -325,13 +338,7 @@ extern "C" int nvx_fetch_bits(nvx_handle *h)
     if (!h) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
-    int rc = collect_locked(h);
-    if (rc == NVX_OK && h->timing && h->ev_valid) {
-        hipEventSynchronize(h->ev[2]);
-        hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[1]);
-        hipEventElapsedTime(&h->ms[1], h->ev[1], h->ev[2]);
-    }
-    return rc;
+    return collect_locked(h);
 }
 
 extern "C" size_t nvx_bit_count(nvx_handle *h, int stream, int chain)
@@ -354,6 +361,15 @@ extern "C" size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out,
 
 extern "C" void nvx_enable_timing(nvx_handle *h, int enabled) { if (h) h->timing = enabled != 0; }
 extern "C" float nvx_last_kernel_ms(nvx_handle *h, int which) { return (h && which >= 0 && which < 2) ? h->ms[which] : -1.f; }
+extern "C" int nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, uint64_t *launches, int reset)
+{
+    if (!h || which < 0 || which > 1) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (sum_ms) *sum_ms = h->ms_sum[which];
+    if (launches) *launches = h->ms_count;
+    if (reset) { h->ms_sum[0] = h->ms_sum[1] = 0.0; h->ms_count = 0; }
+    return NVX_OK;
+}
 
 extern "C" int nvx_enable_debug(nvx_handle *h, int enabled)
 {

@@ -6,7 +6,7 @@
 //        mixer +-14 kHz         receiver/fir2cpp.C:112-128
 //        FIR2 47 taps /7        receiver/fir2cpp.C:131-215
 //        FIR3 71 taps /10       receiver/fir3cpp.C:22-60
-//   nvx_demod                   900 S/s -> 'B'/'Y' bits
+//   nvx_demod_front + nvx_demod_fsm   900 S/s -> 'B'/'Y' bits
 //        discriminator          receiver/decoder.C:42-59
 //        bit-timing filter      receiver/decoder.C:142-255
 //        mark/space decision    receiver/decoder.C:73-137
@@ -308,108 +308,180 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 }
 
 // ===========================================================================
-// demodulator: one lane per chain, sequential over the block's 900 S/s samples
+// demodulator (receiver/decoder.C), split by what is parallel in time
 // ===========================================================================
-// State layout (struct-of-arrays over chains, nc = number of chain slots):
-//   doubles: prevI, prevQ, dab[9], csa[9], cb[567]      -> field f at d[f*nc + chain]
-//   floats : BR, BI, YR, YI
-//   ints   : see enum below
-enum { DI_BS_SEQ = 0, DI_STATUS, DI_SAMPLECOUNT, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_BURN,
-       DI_DAB_INDEX, DI_CB_INDEX, DI_CSA_INDEX, DI_DAB_PRIMED, DI_CB_PRIMED, DI_CSA_PRIMED,
-       DI_PREV_OFFSET, DI_BD_SEQ, DI_COUNT };
-enum { DD_PREVI = 0, DD_PREVQ = 1, DD_DAB = 2, DD_CSA = 11, DD_CB = 20, DD_COUNT = 20 + 567 };
-static_assert(DI_COUNT == NVX_DEMOD_INTS && DD_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET, "state layout");
+// With g = index of a 900 S/s sample since reset, the reference's counters are
+// pure functions of g (decoder.C:142-255):
+//   delta-phi ring primed at g = 8   -> |corr| value kappa = g - 8 written to
+//                                       ring position kappa mod 567
+//   |corr| ring primed at g = 574    -> one class sum per sample, class
+//                                       c(g) = (g - 574) mod 9, over ring
+//                                       positions c, c+9, ... in ASCENDING
+//                                       POSITION order (not time order)
+//   class sums primed at g = 582     -> arg-max over the 9 sums when
+//                                       (g - 582) mod 9 == 0; at that moment
+//                                       csa[i] = S(g - 8 + i)
+// so delta-phi, |corr|, the class sums S(g) and the arg-max are computed for all
+// samples of a launch in parallel (nvx_demod_front, one workgroup per chain,
+// time-tiled through LDS), and only the two tiny state machines (timing slew
+// limiter, mark/space bit FSM with its five-sample mixed-precision
+// accumulation) run sequentially, one lane per chain (nvx_demod_fsm).
+// Every floating-point sum keeps the reference's operand order.
+//
+// Per-slot double state (AoS): prevI, prevQ, last 8 delta-phi, last 8 class
+// sums, last 567 |corr| values in time order.
+enum { DS_PREV = 0, DS_DPHI = 2, DS_S = 10, DS_C = 18, DS_COUNT = 18 + 567 };
+// Per-slot int state (SoA over slots)
+enum { DI_STATUS = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_BURN, DI_SAMPLECOUNT, DI_PREV_OFFSET, DI_COUNT };
+static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET, "state layout");
 
 enum { ST_INIT = 0, ST_WAIT = 1, ST_BIT_START = 2, ST_RECEIVING = 3 };   // decoder.h:16-19
 
-__global__ __launch_bounds__(64) void nvx_demod(nvx_demod_args a)
+#define DTL 1152                         // time tile: 4 frames of 900 S/s samples
+#define G_DAB 8
+#define G_CB 574
+#define G_CSA 582
+
+__global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
 {
-    __shared__ double s_dab[9][64];
-    __shared__ double s_csa[9][64];
-    const int tid = threadIdx.x;
-    const int slot = blockIdx.x * 64 + tid;
+    __shared__ double s_dphi[8 + DTL];
+    __shared__ double s_S[8 + DTL];
+    __shared__ double s_C[567 + DTL];
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (!a.slot_active[slot]) return;                    // uniform over the block
+
+    double *st = a.dstate + (size_t)slot * NVX_DEMOD_DOUBLES;
+    const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
+    double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
+    const double prevI0 = st[DS_PREV], prevQ0 = st[DS_PREV + 1];
+    if (tid < 8) { s_dphi[tid] = st[DS_DPHI + tid]; s_S[tid] = st[DS_S + tid]; }
+    for (int i = tid; i < 567; i += 256) s_C[i] = st[DS_C + i];
+    __syncthreads();
+
+    for (int ta = 0; ta < a.n3; ta += DTL) {
+        const int tl = min(DTL, a.n3 - ta);
+        const unsigned long long gt = a.g0 + (unsigned long long)ta;     // g of L = 0
+        // ---- discriminator, decoder.C:48-52
+        for (int L = tid; L < tl; L += 256) {
+            const int t = ta + L;
+            const double2 s = y3[t];
+            double pI = prevI0, pQ = prevQ0;
+            if (t > 0) { const double2 p = y3[t - 1]; pI = p.x; pQ = p.y; }
+            const double prodReal = s.x * pI + s.y * pQ;
+            const double prodImg  = s.y * pI - s.x * pQ;
+            const double ds = nvx_atan2(prodImg, prodReal);
+            s_dphi[8 + L] = ds;
+            if (dphi_out) dphi_out[t] = ds;
+        }
+        __syncthreads();
+        // ---- transition correlator, decoder.C:157-177: mask[i] * dphi[g-8+i], i ascending
+        for (int L = tid; L < tl; L += 256) {
+            if (gt + L >= G_DAB) {
+                double temp = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) temp += (double)NVX_CORR_MASK[i] * s_dphi[L + i];
+                s_C[567 + L] = __builtin_fabs(temp);
+            } else {
+                s_C[567 + L] = 0.0;                      // never read; keeps the carried state deterministic
+            }
+        }
+        __syncthreads();
+        // ---- class sum, decoder.C:181-197: ring positions c, c+9, ... ascending.
+        // Position p holds the newest value kappa' <= kappa with kappa' = p (mod 567),
+        // i.e. the value d = (kappa - p) mod 567 samples back.
+        for (int L = tid; L < tl; L += 256) {
+            const unsigned long long g = gt + L;
+            if (g >= G_CB) {
+                const unsigned long long kappa = g - 8;
+                const int c = (int)((g - G_CB) % 9);
+                int d = (int)((kappa - c) % 567);
+                double temp = 0.0;
+                for (int j = 0; j < 63; j++) {
+                    temp += s_C[567 + L - d];
+                    d -= 9; if (d < 0) d += 567;
+                }
+                s_S[8 + L] = temp;
+            } else {
+                s_S[8 + L] = 0.0;
+            }
+        }
+        __syncthreads();
+        // ---- arg-max once per bit period, decoder.C:202-215: csa[i] = S(g-8+i),
+        // strict '>' from -1.0 => first maximum wins
+        for (int L = tid; L < tl; L += 256) {
+            const unsigned long long g = gt + L;
+            if (g % 9 == G_CSA % 9) {
+                int max_index = -1;
+                if (g >= G_CSA) {
+                    double temp_max = -1.0;
+                    max_index = 0;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        const double v = s_S[L + i];
+                        if (v > temp_max) { temp_max = v; max_index = i; }
+                    }
+                }
+                a.argmax[(size_t)((ta + L) / 9) * a.n_slots + slot] = (signed char)max_index;
+            }
+        }
+        __syncthreads();
+        // ---- slide the histories to the front for the next tile / the next launch
+        double h_d = 0.0, h_s = 0.0, h_c[3];
+        if (tid < 8) { h_d = s_dphi[tl + tid]; h_s = s_S[tl + tid]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; h_c[k] = (i < 567) ? s_C[tl + i] : 0.0; }
+        __syncthreads();
+        if (tid < 8) { s_dphi[tid] = h_d; s_S[tid] = h_s; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < 567) s_C[i] = h_c[k]; }
+        __syncthreads();
+    }
+
+    if (tid == 0 && a.n3 > 0) { const double2 l = y3[a.n3 - 1]; st[DS_PREV] = l.x; st[DS_PREV + 1] = l.y; }
+    if (tid < 8) { st[DS_DPHI + tid] = s_dphi[tid]; st[DS_S + tid] = s_S[tid]; }
+    for (int i = tid; i < 567; i += 256) st[DS_C + i] = s_C[i];
+}
+
+__global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
+{
+    const int slot = blockIdx.x * 64 + threadIdx.x;
     const int nc = a.n_slots;
     if (slot >= nc) return;
     if (!a.slot_active[slot]) return;
-
-    double *sd = a.state_d;
-    float  *sf = a.state_f;
-    int    *si = a.state_i;
-#define SD(f) sd[(size_t)(f) * nc + slot]
+    float *sf = a.state_f; int *si = a.state_i;
 #define SF(f) sf[(size_t)(f) * nc + slot]
 #define SI(f) si[(size_t)(f) * nc + slot]
-
-    double prevI = SD(DD_PREVI), prevQ = SD(DD_PREVQ);
-    for (int i = 0; i < 9; i++) { s_dab[i][tid] = SD(DD_DAB + i); s_csa[i][tid] = SD(DD_CSA + i); }
     float BR = SF(0), BI = SF(1), YR = SF(2), YI = SF(3);
-    int bs_seq = SI(DI_BS_SEQ), status = SI(DI_STATUS), samplecount = SI(DI_SAMPLECOUNT);
-    int sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF), burn = SI(DI_BURN);
-    int dab_index = SI(DI_DAB_INDEX), cb_index = SI(DI_CB_INDEX), csa_index = SI(DI_CSA_INDEX);
-    int dab_primed = SI(DI_DAB_PRIMED), cb_primed = SI(DI_CB_PRIMED), csa_primed = SI(DI_CSA_PRIMED);
-    int prev_offset = SI(DI_PREV_OFFSET), bd_seq = SI(DI_BD_SEQ);
+    int status = SI(DI_STATUS), sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF);
+    int burn = SI(DI_BURN), samplecount = SI(DI_SAMPLECOUNT), prev_offset = SI(DI_PREV_OFFSET);
 
     const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
     uint8_t *bits = a.bits + (size_t)slot * a.bits_cap;
-    double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
     int nbits = 0;
+    int gmod9 = (int)(a.g0 % 9);                 // g mod 9 of the current sample
+    unsigned long long g = a.g0;
 
-    for (int t = 0; t < a.n3; t++) {
-        const double2 s = y3[t];
-        // ---- discriminator, decoder.C:48-55
-        const double prodReal = s.x * prevI + s.y * prevQ;
-        const double prodImg  = s.y * prevI - s.x * prevQ;
-        const double ds = nvx_atan2(prodImg, prodReal);
-        prevI = s.x; prevQ = s.y;
-        if (dphi_out) dphi_out[t] = ds;
-
-        // ---- bit-timing filter, decoder.C:142-255
-        s_dab[dab_index][tid] = ds;
-        if (++dab_index == 9) { dab_index = 0; dab_primed = 1; }
-        if (dab_primed) {
-            double temp = 0.0;
-            int j = dab_index;
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                temp += (double)NVX_CORR_MASK[i] * s_dab[j][tid];
-                if (++j == 9) j = 0;
-            }
-            SD(DD_CB + cb_index) = __builtin_fabs(temp);
-            if (++cb_index == 567) { cb_index = 0; cb_primed = 1; }
-        }
-        if (cb_primed) {
-            double temp = 0.0;
-            for (int i = csa_index; i < 567; i += 9) temp += SD(DD_CB + i);
-            s_csa[csa_index][tid] = temp;
-            if (++csa_index == 9) { csa_index = 0; csa_primed = 1; }
-        }
-        if (csa_primed) {
-            if (bs_seq == 0) {
-                double temp_max = -1.0;
-                int max_index = 0;
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    const double v = s_csa[i][tid];
-                    if (v > temp_max) { temp_max = v; max_index = i; }
+    for (int t = 0; t < a.n3; t++, g++) {
+        // ---- timing decision, decoder.C:202-249 (the arg-max itself is precomputed)
+        if (gmod9 == G_CSA % 9 && g >= G_CSA) {
+            int max_index = a.argmax[(size_t)(t / 9) * nc + slot];
+            if (!(prev_offset == -1 || max_index == prev_offset)) {
+                if (max_index > prev_offset) {
+                    if (max_index - prev_offset > 4) max_index = (prev_offset - 1 + 9) % 9;
+                    else                             max_index = (prev_offset + 1) % 9;
+                } else {
+                    if (prev_offset - max_index > 4) max_index = (prev_offset + 1) % 9;
+                    else                             max_index = (prev_offset - 1 + 9) % 9;
                 }
-                if (!(prev_offset == -1 || max_index == prev_offset)) {
-                    if (max_index > prev_offset) {
-                        if (max_index - prev_offset > 4) max_index = (prev_offset - 1 + 9) % 9;
-                        else                             max_index = (prev_offset + 1) % 9;
-                    } else {
-                        if (prev_offset - max_index > 4) max_index = (prev_offset + 1) % 9;
-                        else                             max_index = (prev_offset - 1 + 9) % 9;
-                    }
-                }
-                prev_offset = max_index;
-                const int offset = (max_index + 5) % 9;          // decoder.C:249
-                if (status == ST_INIT) { status = ST_WAIT; sync_off = offset; }   // decoder.C:62-70
-                next_sync_off = offset;
             }
-            if (++bs_seq == 9) bs_seq = 0;
+            prev_offset = max_index;
+            const int offset = (max_index + 5) % 9;                               // decoder.C:249
+            if (status == ST_INIT) { status = ST_WAIT; sync_off = offset; }       // decoder.C:62-70
+            next_sync_off = offset;
         }
-
-        // ---- mark/space decision, decoder.C:73-137 (bd_seq kept modulo 9)
-        if (++bd_seq == 9) bd_seq = 0;
+        // ---- mark/space decision, decoder.C:73-137; bd_seq_nbr = g + 1
+        const int bd_seq = (gmod9 + 1 == 9) ? 0 : gmod9 + 1;
+        if (++gmod9 == 9) gmod9 = 0;
         if (status == ST_INIT) continue;
         if (status == ST_WAIT && bd_seq == sync_off) { status = ST_BIT_START; burn = 0; }
         if (status == ST_BIT_START) {
@@ -425,6 +497,7 @@ __global__ __launch_bounds__(64) void nvx_demod(nvx_demod_args a)
             float fR = 0.0f, fI = 0.0f;
 #pragma unroll
             for (int i = 0; i < 5; i++) if (samplecount == i) { fR = NVX_BF_R[i]; fI = NVX_BF_I[i]; }
+            const double2 s = y3[t];
             const double sampleR = s.x, sampleI = s.y;
             // decoder.C:115-118: float*float product, double*float product,
             // double sum, accumulate in double, round to float
@@ -444,15 +517,9 @@ __global__ __launch_bounds__(64) void nvx_demod(nvx_demod_args a)
     }
 
     a.nbits[slot] = nbits;
-    SD(DD_PREVI) = prevI; SD(DD_PREVQ) = prevQ;
-    for (int i = 0; i < 9; i++) { SD(DD_DAB + i) = s_dab[i][tid]; SD(DD_CSA + i) = s_csa[i][tid]; }
     SF(0) = BR; SF(1) = BI; SF(2) = YR; SF(3) = YI;
-    SI(DI_BS_SEQ) = bs_seq; SI(DI_STATUS) = status; SI(DI_SAMPLECOUNT) = samplecount;
-    SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off; SI(DI_BURN) = burn;
-    SI(DI_DAB_INDEX) = dab_index; SI(DI_CB_INDEX) = cb_index; SI(DI_CSA_INDEX) = csa_index;
-    SI(DI_DAB_PRIMED) = dab_primed; SI(DI_CB_PRIMED) = cb_primed; SI(DI_CSA_PRIMED) = csa_primed;
-    SI(DI_PREV_OFFSET) = prev_offset; SI(DI_BD_SEQ) = bd_seq;
-#undef SD
+    SI(DI_STATUS) = status; SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off;
+    SI(DI_BURN) = burn; SI(DI_SAMPLECOUNT) = samplecount; SI(DI_PREV_OFFSET) = prev_offset;
 #undef SF
 #undef SI
 }
@@ -518,8 +585,10 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
 
 extern "C" hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s)
 {
-    dim3 grid((unsigned)((a->n_slots + 63) / 64)), block(64);
-    hipLaunchKernelGGL(nvx_demod, grid, block, 0, s, *a);
+    hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(256), 0, s, *a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nvx_demod_fsm, dim3((unsigned)((a->n_slots + 63) / 64)), dim3(64), 0, s, *a);
     return hipGetLastError();
 }
 

@@ -659,7 +659,7 @@ int nvxo_max_threads(void)
 }
 
 double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int chain_mask,
-                  int nthreads, char *bits_out, size_t cap)
+                  int nthreads, int repeat, char *bits_out, size_t cap)
 {
     struct timespec t0, t1;
     size_t stride = (raw ? n * NVXO_D0 : n) * 2;
@@ -668,12 +668,13 @@ double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int cha
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
 #endif
-    for (long s = 0; s < (long)nstreams; s++) {
+    for (long job = 0; job < (long)nstreams * repeat; job++) {
+        const long s = job % (long)nstreams;            /* the same sample, `repeat` times over */
         nvxo_pipe *p = nvxo_pipe_new(chain_mask, 518, 490, NULL, NULL);
         nvxo_pipe_set_charlayer(p, 0);
         if (raw) nvxo_pipe_push_raw(p, iq + (size_t)s * stride, n);
         else     nvxo_pipe_push(p, iq + (size_t)s * stride, n);
-        if (bits_out) {
+        if (bits_out && job < (long)nstreams) {
             size_t nb; const char *b = nvxo_pipe_bits(p, (chain_mask & 1) ? 0 : 1, &nb);
             if (nb >= cap) nb = cap - 1;
             memcpy(bits_out + (size_t)s * cap, b, nb); bits_out[(size_t)s * cap + nb] = 0;

@@ -95,10 +95,12 @@ void       nvxo_pipe_set_charlayer(nvxo_pipe *p, int enabled);
 
 /* ---- timed CPU baseline: nstreams independent streams, OpenMP over streams.
  * raw=1: iq is [nstreams][n*8] at 2.016 MS/s (stage 0 included), else
- * [nstreams][n] at 252 kS/s.  Returns seconds; fills bits_out[nstreams][cap]
+ * [nstreams][n] at 252 kS/s.  The whole sample is processed `repeat` times
+ * (fresh state each time) so a bounded sample can fill a timing window.
+ * Returns seconds; fills bits_out[nstreams][cap]
  * with NUL-terminated strings of chain 0 when non-NULL.                       */
 double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int chain_mask,
-                  int nthreads, char *bits_out, size_t cap);
+                  int nthreads, int repeat, char *bits_out, size_t cap);
 int    nvxo_max_threads(void);
 
 #ifdef __cplusplus

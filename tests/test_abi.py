@@ -1,0 +1,84 @@
+"""The C-ABI boundary: the library loads without a GPU, exports every symbol
+include/navtex_amd.h declares, and its device entry points fail loudly (no CPU
+fallback) when there is no device.  CPU only -- no compute calls."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "navtex_amd.h").read_text()
+
+
+def declared_symbols():
+    names = set(re.findall(r"NVX_API\s+[\w\s\*]+?\b(\w+)\s*\(", HEADER))
+    names |= {"add_message"}                     # declared without NVX_API (weak default sink)
+    return sorted(names)
+
+
+def test_header_declares_the_reference_surface():
+    names = declared_symbols()
+    for sym in ("init_fir_filter1", "sample_in_1", "init_fir2_wrapper", "add_message", "nvx_StreamACallback",
+                "nvx_create", "nvx_push_iq", "nvx_push_planar", "nvx_poll_bits", "nvx_flush", "nvx_destroy",
+                "nvx_wav_open", "nvx_wav_read", "nvx_sitor_receive_bit"):
+        assert sym in names
+    assert len(names) > 50
+
+
+@pytest.mark.parametrize("sym", declared_symbols())
+def test_symbol_is_exported(nv, sym):
+    assert hasattr(nv.lib, sym), f"{sym} is declared in navtex_amd.h but not exported by libnavtex_amd.so"
+
+
+def test_no_torch_or_cxx_types_in_signatures():
+    body = HEADER[HEADER.index("extern \"C\""):]
+    assert "torch" not in body and "std::" not in body and "#include <hip" not in HEADER
+    # the only includes are the two freestanding C headers
+    assert re.findall(r"#include\s+<([^>]+)>", HEADER) == ["stddef.h", "stdint.h"]
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "navtex_amd.h"\nint main(void){ nvx_config c; nvx_config_default(&c); return c.n_streams != 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", "-c", str(src), "-o", str(tmp_path / "t.o")],
+                   check=True)
+
+
+def test_links_against_a_c_program_with_its_own_add_message(nv, tmp_path):
+    """The drop-in claim at link level: a C program that defines add_message (as the
+    receiver's message_store.o does) and calls the three reference symbols links against
+    the library, and the library's weak default does not clash."""
+    src = tmp_path / "host.c"
+    src.write_text("""
+        void init_fir_filter1(void); void sample_in_1(double, double); void init_fir2_wrapper(void);
+        int add_message(char *bbbb, char *message, int freq) { (void)bbbb; (void)message; return freq; }
+        int main(int argc, char **argv) { (void)argv; if (argc > 99) { init_fir_filter1(); init_fir2_wrapper(); sample_in_1(1.0, 2.0); } return 0; }
+    """)
+    exe = tmp_path / "host"
+    lib = ROOT / "navtex_amd"
+    subprocess.run(["gcc", str(src), "-o", str(exe), f"-L{lib}", "-lnavtex_amd", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    subprocess.run([str(exe)], check=True)
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu(nv):
+    if nv.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(nv.NvxError) as e:
+        nv.Pipeline()
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+    st = nv.make_stream([], seed=1, noise_amp=10)
+    assert nv.lib.nvx_synth_device(0, C.byref(st), 1, nv.RATE_IN, 16, C.c_void_p(16), 16) == -2
+    assert nv.lib.nvx_device_alloc(0, 16) is None
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under navtex_amd/ or include/ may
+    include, link or name it."""
+    for path in list((ROOT / "navtex_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if path.is_file() and path.suffix in {".c", ".cpp", ".h", ".hip", ".py"}:
+            text = path.read_text(errors="replace")
+            assert "nvx_oracle" not in text and "nvxo_" not in text and "oracle_binding" not in text, path
+    out = subprocess.run(["ldd", str(ROOT / "navtex_amd" / "libnavtex_amd.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

