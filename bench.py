@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-charlayer", action="store_true")
+    ap.add_argument("--pitch-pad", type=int, default=0, help="extra complex samples between streams (multiple of 4)")
     return ap.parse_args()
 
 
@@ -72,8 +73,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
     device = local
     S, F = args.streams, args.frames
-    pitch = F * nv.FRAME_RAW
-    samples_per_step = S * pitch
+    n_per_stream = F * nv.FRAME_RAW
+    pitch = n_per_stream + args.pitch_pad
+    samples_per_step = S * n_per_stream
     bytes_per_step = samples_per_step * BYTES_PER_SAMPLE
 
     # ---- synthetic input, generated on the device, resident in HBM ----------
@@ -83,8 +85,8 @@ def main():
         gid = rank * S + s                                     # global stream id: subsets per GPU
         st, _ = signals.stream_params(nv, gid, nv.RATE_RAW)
         streams.append(st)
-    buf = nv.DeviceBuffer(bytes_per_step, device=device)
-    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    buf = nv.DeviceBuffer(S * pitch * BYTES_PER_SAMPLE, device=device)
+    nv.synth_device(streams, nv.RATE_RAW, n_per_stream, buf, pitch)
     t_gen = time.time() - t0
 
     pipe = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F,

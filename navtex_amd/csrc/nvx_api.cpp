@@ -86,6 +86,8 @@ struct nvx_handle {
     double2 *d_y3 = nullptr;
     double *d_dd = nullptr, *d_dphi = nullptr; float *d_df = nullptr; int *d_di = nullptr;
     signed char *d_argmax = nullptr;
+    int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
+    int *h_status = nullptr;           // pinned copy of the status word of the last launch
     unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
     Result res[RESULT_SLOTS];
     uint64_t launched = 0, collected = 0;
@@ -139,7 +141,8 @@ static void free_handle(nvx_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3);
-    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_argmax);
+    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_argmax); hipFree(h->d_ctrl);
+    if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
         hipFree(r.d_bits); hipFree(r.d_nbits);
         if (r.h_bits) hipHostFree(r.h_bits);
@@ -214,6 +217,9 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMalloc(&h->d_df, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
     CR_TRY(hipMalloc(&h->d_argmax, (size_t)(h->y3_cap / 9) * h->n_slots));
+    CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
+    CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * sizeof(int), hipHostMallocDefault));
+    memset(h->h_status, 0, RESULT_SLOTS * sizeof(int));
     for (auto &r : h->res) {
         CR_TRY(hipMalloc(&r.d_bits, (size_t)h->n_slots * h->bits_cap));
         CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
@@ -274,6 +280,7 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
     ca.state = h->d_cstate; ca.y3 = h->d_y3; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     nvx_demod_args da{};
     da.y3 = h->d_y3; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
@@ -286,6 +293,7 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
     HIP_TRY(nvx_launch_demod(&da, st));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], st));
+    HIP_TRY(hipMemcpyAsync(h->h_status + (h->launched % RESULT_SLOTS), h->d_ctrl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(r.done, st));
@@ -303,6 +311,10 @@ static int collect_locked(nvx_handle *h)
         Result &r = h->res[h->collected % RESULT_SLOTS];
         if (r.pending) {
             HIP_TRY(hipEventSynchronize(r.done));
+            if (h->h_status[h->collected % RESULT_SLOTS] != 0) {
+                nvx_set_error("FIR cascade work queue: a wait on the previous frame of a stream timed out");
+                return NVX_ERR_HIP;
+            }
             if (r.timed) {
                 HIP_TRY(hipEventElapsedTime(&h->ms[0], r.ev[0], r.ev[1]));
                 HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[1], r.ev[2]));

@@ -7,6 +7,8 @@
 #include "nvx_synth.h"
 
 #define NVX_PASSES_PER_FRAME 315          /* 20160 FIR1 outputs per frame / 64 per pass */
+#define NVX_Y3_PER_FRAME 288
+#define NVX_CASCADE_CTRL_INTS 2           /* [0] work-queue counter, [1] status (non-zero = spin timeout) */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
  * outputs and 70 FIR2 outputs, all fp64 pairs                                 */
 #define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70))
@@ -26,6 +28,9 @@ typedef struct {
     uint8_t *state;            /* [n_streams][NVX_CASCADE_STATE_BYTES]                 */
     double2 *y3;               /* [n_streams*2][y3_cap]                                */
     size_t y3_cap, y3_base;
+    int *queue;                /* NVX_CASCADE_CTRL_INTS control ints followed by ...   */
+    int *status;               /* = queue + 1                                          */
+    int *done;                 /* = queue + 2: frames completed per stream             */
 } nvx_cascade_args;
 
 typedef struct {

@@ -41,6 +41,7 @@
 //     just the three filter histories.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "nvx_tables.h"
 #include "nvx_atan2.h"
@@ -88,64 +89,58 @@ __device__ __forceinline__ int dpp_swap_pairs(int v)
 }
 
 // stage 0 for one 1-KiB load: lane l holds raw samples 4l..4l+3 of the KiB;
-// lanes (2i, 2i+1) together hold the 8 samples of output i.  Even lanes end
-// up with the I sum, odd lanes with the Q sum, already rounded and shifted.
-__device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
+// lanes (2i, 2i+1) together hold the 8 samples of output i.  Even lanes produce
+// the I sum, odd lanes the Q sum: each lane adds up ITS component of its own
+// four samples (mine) and the PARTNER's component of them (other), then one DPP
+// pair-swap add completes both sums.  The selectors are per-lane registers
+// ((1,0) picks I, (0,1) picks Q), so no v_cndmask is needed.
+__device__ __forceinline__ double stage0_component(u32x4 v, nvx_short2 sel_mine, nvx_short2 sel_other)
 {
-    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };
-    int sI = 2, sQ = 2;                       // 2 + 2 = the +4 of round-half-up
-    sI = __builtin_amdgcn_sdot2(as_short2(v.x), selI, sI, false);
-    sQ = __builtin_amdgcn_sdot2(as_short2(v.x), selQ, sQ, false);
-    sI = __builtin_amdgcn_sdot2(as_short2(v.y), selI, sI, false);
-    sQ = __builtin_amdgcn_sdot2(as_short2(v.y), selQ, sQ, false);
-    sI = __builtin_amdgcn_sdot2(as_short2(v.z), selI, sI, false);
-    sQ = __builtin_amdgcn_sdot2(as_short2(v.z), selQ, sQ, false);
-    sI = __builtin_amdgcn_sdot2(as_short2(v.w), selI, sI, false);
-    sQ = __builtin_amdgcn_sdot2(as_short2(v.w), selQ, sQ, false);
-    int keep = odd ? sQ : sI;
-    int give = odd ? sI : sQ;
-    int tot = keep + dpp_swap_pairs(give);
+    int mine = 2, other = 2;                  // 2 + 2 = the +4 of round-half-up
+    mine  = __builtin_amdgcn_sdot2(as_short2(v.x), sel_mine,  mine,  false);
+    other = __builtin_amdgcn_sdot2(as_short2(v.x), sel_other, other, false);
+    mine  = __builtin_amdgcn_sdot2(as_short2(v.y), sel_mine,  mine,  false);
+    other = __builtin_amdgcn_sdot2(as_short2(v.y), sel_other, other, false);
+    mine  = __builtin_amdgcn_sdot2(as_short2(v.z), sel_mine,  mine,  false);
+    other = __builtin_amdgcn_sdot2(as_short2(v.z), sel_other, other, false);
+    mine  = __builtin_amdgcn_sdot2(as_short2(v.w), sel_mine,  mine,  false);
+    other = __builtin_amdgcn_sdot2(as_short2(v.w), sel_other, other, false);
+    const int tot = mine + dpp_swap_pairs(other);
     return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
 }
 
-template <bool RAW>
+template <bool RAW, bool NT>
 __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 *src)
 {
     // src already points at this lane's first 16 bytes of the pass
     if (RAW) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) pf[j] = __builtin_nontemporal_load(src + 64 * j);
+        for (int j = 0; j < 8; j++) pf[j] = NT ? __builtin_nontemporal_load(src + 64 * j) : src[64 * j];
     } else {
-        pf[0] = __builtin_nontemporal_load(src);
+        pf[0] = NT ? __builtin_nontemporal_load(src) : src[0];
     }
 }
 
-template <bool RAW, int NCH>
+// Work distribution: a persistent grid (as many single-wave workgroups as fit
+// on the chip) pulls units u = frame * n_streams + stream from an atomic
+// counter.  A unit is one frame (315 passes, 2.5 MiB raw) of one stream; the
+// FIR histories travel from unit (stream, f) to (stream, f+1) through the
+// per-stream state block in HBM, ordered by done[stream] with the agent-scope
+// release / acquire protocol (the two units usually run on different CUs).
+// Units are handed out frame-major, so a unit's predecessor was taken n_streams
+// units earlier by a workgroup that is already running: the wait cannot
+// deadlock whatever the residency, and every spin is bounded anyway.
+// Why: LDS limits residency to 11 waves per CU (2816), so 4096 equal-length
+// per-stream jobs would run as a VALU-saturated first round and a
+// latency-bound tail of 1280; frame-sized units keep every CU full to the end.
+#define NVX_SPIN_LIMIT (1 << 22)
+
+template <bool RAW, int NCH, int PFD, bool NT>
 __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 {
     __shared__ CascadeLds<NCH> lds;
     const int lane = threadIdx.x;
-    const int stream = blockIdx.x;
-    if (stream >= a.n_streams) return;
 
-    const unsigned mask = a.chain_masks[stream];
-    // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
-    const int chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
-
-    // ---------------------------------------------------------- state in
-    double2 *st = (double2 *)(a.state + (size_t)stream * NVX_CASCADE_STATE_BYTES);
-    if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
-        int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
-        lds.X[r * XS + e] = st[lane];
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int ch = (NCH == 1) ? chain_of_slot0 : c;
-        const double2 *su = st + 36 + ch * (46 + 70);
-        if (lane < 46) lds.U[c][lane] = su[lane];
-        lds.Y2[c][lane] = su[46 + lane];
-        if (lane < 6) lds.Y2[c][64 + lane] = su[46 + 64 + lane];
-    }
     if (lane < NVX_MIX_N) {
         // constant-index selects keep the tables out of scratch
         double cr = 0.0, ci = 0.0;
@@ -153,157 +148,229 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         for (int j = 0; j < NVX_MIX_N; j++) if (lane == j) { cr = NVX_MIX_CR[j]; ci = NVX_MIX_CI[j]; }
         lds.mix[lane] = cr; lds.mix[NVX_MIX_N + lane] = ci;
     }
-    NVX_WAVE_LDS_FENCE();
 
-    // ---------------------------------------------------------- addressing
+    // ------------------------------------------------------ lane constants
     const size_t pass_words = RAW ? 2048 : 256;    // 32-bit IQ words per pass
-    const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + lane;
-    const int total_passes = a.n_frames * NVX_PASSES_PER_FRAME;
-
+    const size_t pass_stride = pass_words / 4;     // in 16-byte units
+    constexpr int NPF = RAW ? 8 : 1;
     // stage-0 write slot of this lane (RAW): output m = 32j + (lane>>1):
     // phase r = m & 3, index k' = m >> 2 = 8j + (lane>>3), component = lane & 1
     double *xw = (double *)&lds.X[((lane >> 1) & 3) * XS + 9 + (lane >> 3)] + (lane & 1);
     const bool odd = lane & 1;
+    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };
+    const nvx_short2 sel_mine = odd ? selQ : selI, sel_other = odd ? selI : selQ;
     // FIR1 read base of this lane: X[r*XS + 9 + lane - q]
     const double2 *xr = &lds.X[9 + lane];
     // FIR2 / FIR3: lane = 2*output + component
     const int half = lane >> 1, comp = lane & 1;
-    int lane_mod9 = lane % 9;
+    const int lane_mod9 = lane % 9;
+    const int n_units = a.n_streams * a.n_frames;
 
-    u32x4 pf[RAW ? 8 : 1];
-    load_pass<RAW>(pf, src);
+    for (;;) {
+        // ------------------------------------------------------ next unit
+        int u = 0;
+        if (lane == 0) u = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int frame = u / a.n_streams;
+        const int stream = u - frame * a.n_streams;
 
-    int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = 0;
+        const unsigned mask = a.chain_masks[stream];
+        // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
+        const int chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
 
-    for (int pass = 0; pass < total_passes; pass++) {
-        // ---- 1. new 252 kS/s samples into the polyphase window ----------
-        if (RAW) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], odd);       // +8 double2 entries per load
-        } else {
-            // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
-            const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double2 v;
-                v.x = (double)(int)(short)(w[r] & 0xffffu);       // capt_sched.c:511 (double) of each short
-                v.y = (double)((int)w[r] >> 16);
-                lds.X[r * XS + 9 + lane] = v;
+        // the input does not depend on the predecessor: request the first pass(es) now
+        const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) +
+                           (size_t)frame * NVX_PASSES_PER_FRAME * pass_stride + lane;
+        u32x4 pfA[NPF], pfB[NPF];
+        load_pass<RAW, NT>(pfA, src);
+        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
+        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
+
+        // ------------------------------------------------------ wait for (stream, frame-1)
+        if (frame > 0) {
+            int spins = 0, ok = 0;
+            do {
+                int d = 0;
+                if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = __builtin_amdgcn_readfirstlane(d);
+                ok = d >= frame;
+                if (!ok) __builtin_amdgcn_s_sleep(32);
+            } while (!ok && ++spins < NVX_SPIN_LIMIT);
+            if (!ok) {                                   // give up loudly rather than hang the GPU
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
             }
+            // one agent-scope acquire per unit: the state lines may sit stale in this CU's L1
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // ---- 2. prefetch the next pass ------------------------------------
-        src += pass_words / 4;
-        if (pass + 1 < total_passes) load_pass<RAW>(pf, src);
-        NVX_WAVE_LDS_FENCE();
 
-        // ---- 3. FIR1: y1[k] = sum_i h1[i] * x[4k+3-i] ----------------------
-        double aI = 0.0, aQ = 0.0;
-#pragma unroll
-        for (int i = 0; i < NVX_T1; i++) {
-            const int q = i >> 2, r = 3 - (i & 3);
-            double2 x = xr[r * XS - q];
-            aI += NVX_H1[i] * x.x;
-            aQ += NVX_H1[i] * x.y;
+        // ------------------------------------------------------ state in
+        double2 *st = (double2 *)(a.state + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+        NVX_WAVE_LDS_FENCE();
+        if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
+            int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
+            lds.X[r * XS + e] = st[lane];
         }
-        // ---- 4. mixer, table index (k mod 9), k counted from stream start --
-        int j9 = mixbase + lane_mod9; if (j9 >= NVX_MIX_N) j9 -= NVX_MIX_N;
-        const double cr = lds.mix[j9], ci = lds.mix[NVX_MIX_N + j9];
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
-            double2 u;
-            if (ch == 0) {                 // 518 chain, fir2cpp.C:116-117
-                u.x = aI * cr - aQ * ci;
-                u.y = aI * ci + aQ * cr;
-            } else {                       // 490 chain, fir2cpp.C:122-123
-                u.x = aI * cr + aQ * ci;
-                u.y = -aI * ci + aQ * cr;
-            }
-            lds.U[c][46 + n_u + lane] = u;
-        }
-        n_u += 64;
-        mixbase += 1; if (mixbase == NVX_MIX_N) mixbase = 0;      // 64 mod 9 == 1
-        // ---- 5. slide the 9-deep history of each phase to the front --------
-        NVX_WAVE_LDS_FENCE();
-        if (lane < 36) {
-            int e = lane >> 2, r = lane & 3;
-            double2 t = lds.X[r * XS + 64 + e];
-            lds.X[r * XS + e] = t;
+            const double2 *su = st + 36 + ch * (46 + 70);
+            if (lane < 46) lds.U[c][lane] = su[lane];
+            lds.Y2[c][lane] = su[46 + lane];
+            if (lane < 6) lds.Y2[c][64 + lane] = su[46 + 64 + lane];
         }
         NVX_WAVE_LDS_FENCE();
 
-        // ---- 6. FIR2 when 224 mixer outputs are pending ---------------------
-        while (n_u >= U_RUN) {
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                if (NCH == 2 && !((mask >> c) & 1u)) continue;
-                const double *ub = (const double *)&lds.U[c][7 * half] + comp;
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < NVX_T2; i++) acc += NVX_H2[i] * ub[2 * (52 - i)];
-                ((double *)&lds.Y2[c][70 + n_y2 + half])[comp] = acc;
-            }
-            NVX_WAVE_LDS_FENCE();
-            // drop the 224 consumed inputs: keep 46 history + pending
-            const int keep = 46 + n_u - U_RUN;                  // <= 109
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                double2 t0 = lds.U[c][U_RUN + lane];
-                double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 48) ? lane : 47)];
-                NVX_WAVE_LDS_FENCE();
-                if (lane < keep) lds.U[c][lane] = t0;
-                if (lane + 64 < keep) lds.U[c][64 + lane] = t1;
-            }
-            NVX_WAVE_LDS_FENCE();
-            n_u -= U_RUN;
-            n_y2 += 32;
+        int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = 0;
+        const size_t y3_row0 = (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)frame * NVX_Y3_PER_FRAME;
 
-            // ---- 7. FIR3 when 160 FIR2 outputs are pending ------------------
-            if (n_y2 >= Y2_RUN) {
+        auto body = [&](u32x4 (&pf)[NPF], const int pass) {
+            // ---- 1. new 252 kS/s samples into the polyphase window ----------
+            if (RAW) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], sel_mine, sel_other);   // +8 double2 entries per load
+            } else {
+                // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
+                const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    double2 v;
+                    v.x = (double)(int)(short)(w[r] & 0xffffu);       // capt_sched.c:511 (double) of each short
+                    v.y = (double)((int)w[r] >> 16);
+                    lds.X[r * XS + 9 + lane] = v;
+                }
+            }
+            // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
+            if (pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
+            nxt += pass_stride;
+            NVX_WAVE_LDS_FENCE();
+
+            // ---- 3. FIR1: y1[k] = sum_i h1[i] * x[4k+3-i] ----------------------
+            double aI = 0.0, aQ = 0.0;
+#pragma unroll
+            for (int i = 0; i < NVX_T1; i++) {
+                const int q = i >> 2, r = 3 - (i & 3);
+                double2 x = xr[r * XS - q];
+                aI += NVX_H1[i] * x.x;
+                aQ += NVX_H1[i] * x.y;
+            }
+            // ---- 4. mixer, table index (k mod 9), k counted from the frame start
+            // (a frame is 20160 = 9 * 2240 FIR1 outputs, so that equals k from stream start)
+            int j9 = mixbase + lane_mod9; if (j9 >= NVX_MIX_N) j9 -= NVX_MIX_N;
+            const double cr = lds.mix[j9], ci = lds.mix[NVX_MIX_N + j9];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                double2 uu;
+                if (ch == 0) {                 // 518 chain, fir2cpp.C:116-117
+                    uu.x = aI * cr - aQ * ci;
+                    uu.y = aI * ci + aQ * cr;
+                } else {                       // 490 chain, fir2cpp.C:122-123
+                    uu.x = aI * cr + aQ * ci;
+                    uu.y = -aI * ci + aQ * cr;
+                }
+                lds.U[c][46 + n_u + lane] = uu;
+            }
+            n_u += 64;
+            mixbase += 1; if (mixbase == NVX_MIX_N) mixbase = 0;      // 64 mod 9 == 1
+            // ---- 5. slide the 9-deep history of each phase to the front --------
+            NVX_WAVE_LDS_FENCE();
+            if (lane < 36) {
+                int e = lane >> 2, r = lane & 3;
+                double2 t = lds.X[r * XS + 64 + e];
+                lds.X[r * XS + e] = t;
+            }
+            NVX_WAVE_LDS_FENCE();
+
+            // ---- 6. FIR2 when 224 mixer outputs are pending ---------------------
+            while (n_u >= U_RUN) {
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     if (NCH == 2 && !((mask >> c) & 1u)) continue;
-                    const int ch = (NCH == 1) ? chain_of_slot0 : c;
-                    const int p = half & 15;
-                    const double *yb = (const double *)&lds.Y2[c][10 * p] + comp;
+                    const double *ub = (const double *)&lds.U[c][7 * half] + comp;
                     double acc = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
-                    if (lane < 32) {
-                        double *out = (double *)(a.y3 + ((size_t)(stream * 2 + ch) * a.y3_cap + a.y3_base + n3_done + p));
-                        out[comp] = acc;
-                    }
+                    for (int i = 0; i < NVX_T2; i++) acc += NVX_H2[i] * ub[2 * (52 - i)];
+                    ((double *)&lds.Y2[c][70 + n_y2 + half])[comp] = acc;
                 }
                 NVX_WAVE_LDS_FENCE();
-                const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101
+                // drop the 224 consumed inputs: keep 46 history + pending
+                const int keep = 46 + n_u - U_RUN;                  // <= 109
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
-                    double2 t0 = lds.Y2[c][Y2_RUN + lane];
-                    double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 40) ? lane : 39)];
+                    double2 t0 = lds.U[c][U_RUN + lane];
+                    double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 48) ? lane : 47)];
                     NVX_WAVE_LDS_FENCE();
-                    if (lane < keep3) lds.Y2[c][lane] = t0;
-                    if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
+                    if (lane < keep) lds.U[c][lane] = t0;
+                    if (lane + 64 < keep) lds.U[c][64 + lane] = t1;
                 }
                 NVX_WAVE_LDS_FENCE();
-                n_y2 -= Y2_RUN;
-                n3_done += 16;
-            }
-        }
-    }
+                n_u -= U_RUN;
+                n_y2 += 32;
 
-    // ---------------------------------------------------------- state out
-    NVX_WAVE_LDS_FENCE();
-    if (lane < 36) {
-        int e = lane >> 2, r = lane & 3;
-        st[lane] = lds.X[r * XS + e];
-    }
+                // ---- 7. FIR3 when 160 FIR2 outputs are pending ------------------
+                if (n_y2 >= Y2_RUN) {
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int ch = (NCH == 1) ? chain_of_slot0 : c;
-        double2 *su = st + 36 + ch * (46 + 70);
-        if (lane < 46) su[lane] = lds.U[c][lane];
-        su[46 + lane] = lds.Y2[c][lane];
-        if (lane < 6) su[46 + 64 + lane] = lds.Y2[c][64 + lane];
+                    for (int c = 0; c < NCH; c++) {
+                        if (NCH == 2 && !((mask >> c) & 1u)) continue;
+                        const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                        const int p = half & 15;
+                        const double *yb = (const double *)&lds.Y2[c][10 * p] + comp;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
+                        if (lane < 32) {
+                            double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + p));
+                            out[comp] = acc;
+                        }
+                    }
+                    NVX_WAVE_LDS_FENCE();
+                    const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        double2 t0 = lds.Y2[c][Y2_RUN + lane];
+                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 40) ? lane : 39)];
+                        NVX_WAVE_LDS_FENCE();
+                        if (lane < keep3) lds.Y2[c][lane] = t0;
+                        if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
+                    }
+                    NVX_WAVE_LDS_FENCE();
+                    n_y2 -= Y2_RUN;
+                    n3_done += 16;
+                }
+            }
+        };
+
+        if (PFD == 2) {
+            for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass += 2) {
+                body(pfA, pass);
+                if (pass + 1 < NVX_PASSES_PER_FRAME) body(pfB, pass + 1);
+            }
+        } else {
+            for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass++) body(pfA, pass);
+        }
+
+        // ------------------------------------------------------ state out
+        NVX_WAVE_LDS_FENCE();
+        if (lane < 36) {
+            int e = lane >> 2, r = lane & 3;
+            st[lane] = lds.X[r * XS + e];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int ch = (NCH == 1) ? chain_of_slot0 : c;
+            double2 *su = st + 36 + ch * (46 + 70);
+            if (lane < 46) su[lane] = lds.U[c][lane];
+            su[46 + lane] = lds.Y2[c][lane];
+            if (lane < 6) su[46 + 64 + lane] = lds.Y2[c][64 + lane];
+        }
+        // publish: stores drained, agent-scope release, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.done + stream, frame + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -570,17 +637,43 @@ __global__ __launch_bounds__(256) void nvx_synth_kernel(nvx_synth_args a)
 // ===========================================================================
 // launchers (C linkage, called from nvx_api.cpp)
 // ===========================================================================
+// tuning switches for A/B runs (defaults are the shipped configuration)
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+
+template <bool RAW, int NCH, int PFD, bool NT>
+static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
+{
+    // persistent grid: as many single-wave workgroups as the chip holds at once
+    static int resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 0, per_cu = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nvx_fir_cascade<RAW, NCH, PFD, NT>, 64, 0);
+        if (e != hipSuccess) return e;
+        const int cap = env_int("NVX_WAVES_PER_CU", 0);
+        if (cap > 0 && cap < per_cu) per_cu = cap;
+        resident = cus * (per_cu > 0 ? per_cu : 1);
+    }
+    const long long units = (long long)a->n_streams * a->n_frames;
+    const unsigned grid = (unsigned)(units < resident ? units : resident);
+    hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, *a);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s)
 {
-    dim3 grid((unsigned)a->n_streams), block(64);
-    if (raw) {
-        if (nch == 1) hipLaunchKernelGGL((nvx_fir_cascade<true, 1>), grid, block, 0, s, *a);
-        else          hipLaunchKernelGGL((nvx_fir_cascade<true, 2>), grid, block, 0, s, *a);
-    } else {
-        if (nch == 1) hipLaunchKernelGGL((nvx_fir_cascade<false, 1>), grid, block, 0, s, *a);
-        else          hipLaunchKernelGGL((nvx_fir_cascade<false, 2>), grid, block, 0, s, *a);
-    }
-    return hipGetLastError();
+    static const int pfd = env_int("NVX_PREFETCH", 1) == 2 ? 2 : 1;
+    static const int nt = env_int("NVX_NT", 1) != 0;
+    // queue counter, status word and per-stream completion counts start at zero every launch
+    hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_streams) * sizeof(int), s);
+    if (e != hipSuccess) return e;
+#define NVX_CASE(R, C) ( \
+        pfd == 2 ? (nt ? launch_cascade_as<R, C, 2, true>(a, s) : launch_cascade_as<R, C, 2, false>(a, s)) \
+                 : (nt ? launch_cascade_as<R, C, 1, true>(a, s) : launch_cascade_as<R, C, 1, false>(a, s)))
+    if (raw) return nch == 1 ? NVX_CASE(true, 1) : NVX_CASE(true, 2);
+    return nch == 1 ? NVX_CASE(false, 1) : NVX_CASE(false, 2);
+#undef NVX_CASE
 }
 
 extern "C" hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s)
