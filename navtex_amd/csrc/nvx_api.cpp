@@ -84,8 +84,8 @@ struct nvx_handle {
     // device
     uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
     double2 *d_y3 = nullptr;
-    double *d_dd = nullptr, *d_dphi = nullptr; float *d_df = nullptr; int *d_di = nullptr;
-    signed char *d_argmax = nullptr;
+    double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
+    unsigned short *d_words = nullptr;
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
     int *h_status = nullptr;           // pinned copy of the status word of the last launch
     unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
@@ -141,7 +141,7 @@ static void free_handle(nvx_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3);
-    hipFree(h->d_dd); hipFree(h->d_df); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_argmax); hipFree(h->d_ctrl);
+    hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
         hipFree(r.d_bits); hipFree(r.d_nbits);
@@ -177,7 +177,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     h->n_streams = cfg->n_streams; h->n_slots = 2 * cfg->n_streams;
     h->frame_in = cfg->raw_rate ? (size_t)NVX_FRAME_RAW : (size_t)NVX_FRAME_IN;
     h->y3_cap = cfg->max_frames * NVX_FRAME_Y3;
-    h->bits_cap = h->y3_cap / 8 + 8;            // a bit needs >= 8 samples (offset slews by at most 1)
+    // a bit needs >= 8 samples (the offset slews by at most 1 per bit); packed 8 bits per byte, whole words
+    h->bits_cap = (((h->y3_cap / 8 + 8) + 31) / 32) * 4;
     h->masks.resize(h->n_streams);
     h->slots.resize(h->n_slots);
     bool any_two = false;
@@ -214,9 +215,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMalloc(&h->d_cstate, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
     CR_TRY(hipMalloc(&h->d_y3, (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
     CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
-    CR_TRY(hipMalloc(&h->d_df, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
-    CR_TRY(hipMalloc(&h->d_argmax, (size_t)(h->y3_cap / 9) * h->n_slots));
+    CR_TRY(hipMalloc(&h->d_words, (size_t)(h->y3_cap / 9) * h->n_slots * sizeof(unsigned short)));
     CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
     CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, RESULT_SLOTS * sizeof(int));
@@ -257,10 +257,12 @@ extern "C" int nvx_reset(nvx_handle *h)
     h->g0 = 0;
     HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_df, 0, (size_t)NVX_DEMOD_FLOATS * h->n_slots * sizeof(float), h->stream));
-    // ints: all zero except prev_offset = -1 (decoder.C:30)
+    // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
     std::vector<int> ints((size_t)NVX_DEMOD_INTS * h->n_slots, 0);
-    for (int i = 0; i < h->n_slots; i++) ints[(size_t)NVX_DI_PREV_OFFSET * h->n_slots + i] = -1;
+    for (int i = 0; i < h->n_slots; i++) {
+        ints[(size_t)NVX_DI_PREV_OFFSET * h->n_slots + i] = -1;
+        ints[(size_t)NVX_DI_PHASE * h->n_slots + i] = -1;
+    }
     HIP_TRY(hipMemcpyAsync(h->d_di, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto &s : h->slots) { s.bits.clear(); s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
@@ -284,7 +286,7 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     nvx_demod_args da{};
     da.y3 = h->d_y3; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
-    da.g0 = h->g0; da.dstate = h->d_dd; da.state_f = h->d_df; da.state_i = h->d_di; da.argmax = h->d_argmax;
+    da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.words = h->d_words;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
 
     r.timed = h->timing;
@@ -324,10 +326,12 @@ static int collect_locked(nvx_handle *h)
                 Slot &s = h->slots[i];
                 if (!s.active) continue;
                 int n = r.h_nbits[i];
-                if (n > h->bits_cap) { nvx_set_error("bit buffer overflow on slot %d (%d > %d)", i, n, h->bits_cap); return NVX_ERR_STATE; }
-                const char *b = (const char *)r.h_bits + (size_t)i * h->bits_cap;
-                s.bits.append(b, (size_t)n);
-                if (s.sitor) nvx_sitor_receive_bits(s.sitor, b, (size_t)n);
+                if (n > h->bits_cap * 8) { nvx_set_error("bit buffer overflow on slot %d (%d > %d)", i, n, h->bits_cap * 8); return NVX_ERR_STATE; }
+                const uint32_t *pw = (const uint32_t *)(r.h_bits + (size_t)i * h->bits_cap);
+                const size_t at = s.bits.size();
+                s.bits.resize(at + (size_t)n);
+                for (int k = 0; k < n; k++) s.bits[at + k] = ((pw[k >> 5] >> (k & 31)) & 1u) ? 'B' : 'Y';
+                if (s.sitor) nvx_sitor_receive_bits(s.sitor, s.bits.data() + at, (size_t)n);
             }
             r.pending = false;
         }

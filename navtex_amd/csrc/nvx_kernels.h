@@ -13,10 +13,10 @@
  * outputs and 70 FIR2 outputs, all fp64 pairs                                 */
 #define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70))
 #define NVX_CASCADE_STATE_BYTES   (NVX_CASCADE_STATE_ENTRIES * 16)
-#define NVX_DEMOD_DOUBLES (2 + 8 + 8 + 567) /* per slot, contiguous: prev IQ, dphi, class sums, |corr| */
-#define NVX_DEMOD_FLOATS  4
-#define NVX_DEMOD_INTS    6
-#define NVX_DI_PREV_OFFSET 5            /* int field that resets to -1 (decoder.C:30) */
+#define NVX_DEMOD_DOUBLES (8 + 8 + 8 + 567) /* per slot, contiguous: last 4 IQ, dphi, class sums, |corr| */
+#define NVX_DEMOD_INTS    5
+#define NVX_DI_PHASE       3            /* bit-FSM phase, resets to -1 (waiting)            */
+#define NVX_DI_PREV_OFFSET 4            /* resets to -1 (decoder.C:30)                      */
 
 typedef struct {
     const uint32_t *iq;        /* [n_streams][pitch] packed int16 I | Q<<16            */
@@ -41,9 +41,9 @@ typedef struct {
     const uint8_t *slot_active;
     unsigned long long g0;     /* 900 S/s samples processed since reset (multiple of 288) */
     double *dstate;            /* [n_slots][NVX_DEMOD_DOUBLES]                         */
-    float *state_f; int *state_i;   /* [field][n_slots]                                */
-    signed char *argmax;       /* [n3/9][n_slots] scratch between the two kernels      */
-    uint8_t *bits; int bits_cap; int *nbits;
+    int *state_i;              /* [field][n_slots]                                     */
+    unsigned short *words;     /* [n3/9][n_slots] per-bit-period hand-over, front -> fsm */
+    uint8_t *bits; int bits_cap; int *nbits;   /* bits: packed, B = 1, LSB first; bits_cap bytes (multiple of 4) per slot */
     double *dphi;              /* optional debug tap, same layout as y3 (or NULL)      */
 } nvx_demod_args;
 

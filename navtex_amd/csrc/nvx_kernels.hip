@@ -395,32 +395,49 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 // accumulation) run sequentially, one lane per chain (nvx_demod_fsm).
 // Every floating-point sum keeps the reference's operand order.
 //
-// Per-slot double state (AoS): prevI, prevQ, last 8 delta-phi, last 8 class
-// sums, last 567 |corr| values in time order.
-enum { DS_PREV = 0, DS_DPHI = 2, DS_S = 10, DS_C = 18, DS_COUNT = 18 + 567 };
+// The mark/space decision of a bit depends only on the five consecutive samples
+// of its window (decoder.C:96-125: the sums are zeroed when the window opens),
+// so the decision "if a window ended at sample t" is evaluated for EVERY t in
+// parallel too; the sequential kernel then only picks the one the bit FSM lands
+// on.  Per bit period m the front kernel hands over one 16-bit word:
+//   bits 0..8  decision for a window ending at local sample 9m+k ('B' = 1)
+//   bits 12..15 arg-max of that period's timing evaluation, 15 = none yet
+//
+// Per-slot double state (AoS): last 4 samples {I,Q} (the newest is the
+// discriminator's prevI/prevQ), last 8 delta-phi, last 8 class sums, last 567
+// |corr| values in time order.
+enum { DS_Y3 = 0, DS_DPHI = 8, DS_S = 16, DS_C = 24, DS_COUNT = 24 + 567 };
 // Per-slot int state (SoA over slots)
-enum { DI_STATUS = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_BURN, DI_SAMPLECOUNT, DI_PREV_OFFSET, DI_COUNT };
-static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET, "state layout");
+enum { DI_SYNCED = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_PHASE, DI_PREV_OFFSET, DI_COUNT };
+static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET &&
+              DI_PHASE == NVX_DI_PHASE, "state layout");
 
-enum { ST_INIT = 0, ST_WAIT = 1, ST_BIT_START = 2, ST_RECEIVING = 3 };   // decoder.h:16-19
-
-#define DTL 1152                         // time tile: 4 frames of 900 S/s samples
+#define DTL 1152                         // time tile: 4 frames of 900 S/s samples (multiple of 9)
 #define G_DAB 8
 #define G_CB 574
 #define G_CSA 582
+
+// sample t of the launch, t >= -4: history for negative t
+__device__ __forceinline__ double2 y3_at(const double2 *y3, const double *hist, int t)
+{
+    if (t >= 0) return y3[t];
+    double2 r; r.x = hist[2 * (4 + t)]; r.y = hist[2 * (4 + t) + 1];
+    return r;
+}
 
 __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
 {
     __shared__ double s_dphi[8 + DTL];
     __shared__ double s_S[8 + DTL];
     __shared__ double s_C[567 + DTL];
+    __shared__ unsigned char s_D[DTL];
     const int slot = blockIdx.x, tid = threadIdx.x;
     if (!a.slot_active[slot]) return;                    // uniform over the block
 
     double *st = a.dstate + (size_t)slot * NVX_DEMOD_DOUBLES;
     const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
     double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
-    const double prevI0 = st[DS_PREV], prevQ0 = st[DS_PREV + 1];
+    const double *hist = st + DS_Y3;                     // read in place: only the first 4 samples need it
     if (tid < 8) { s_dphi[tid] = st[DS_DPHI + tid]; s_S[tid] = st[DS_S + tid]; }
     for (int i = tid; i < 567; i += 256) s_C[i] = st[DS_C + i];
     __syncthreads();
@@ -428,17 +445,33 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
     for (int ta = 0; ta < a.n3; ta += DTL) {
         const int tl = min(DTL, a.n3 - ta);
         const unsigned long long gt = a.g0 + (unsigned long long)ta;     // g of L = 0
-        // ---- discriminator, decoder.C:48-52
         for (int L = tid; L < tl; L += 256) {
             const int t = ta + L;
+            // ---- discriminator, decoder.C:48-52
             const double2 s = y3[t];
-            double pI = prevI0, pQ = prevQ0;
-            if (t > 0) { const double2 p = y3[t - 1]; pI = p.x; pQ = p.y; }
-            const double prodReal = s.x * pI + s.y * pQ;
-            const double prodImg  = s.y * pI - s.x * pQ;
+            const double2 p = y3_at(y3, hist, t - 1);
+            const double prodReal = s.x * p.x + s.y * p.y;
+            const double prodImg  = s.y * p.x - s.x * p.y;
             const double ds = nvx_atan2(prodImg, prodReal);
             s_dphi[8 + L] = ds;
             if (dphi_out) dphi_out[t] = ds;
+            // ---- mark/space decision for a window ending here, decoder.C:115-132:
+            // float*float product, double*float product, double sum, accumulate in
+            // double, round to float -- five samples, filter index 0..4
+            float BR = 0.0f, BI = 0.0f, YR = 0.0f, YI = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const double2 w = (i == 4) ? s : ((i == 3) ? p : y3_at(y3, hist, t - 4 + i));
+                const float fR = NVX_BF_R[i], fI = NVX_BF_I[i];
+                const double sampleR = w.x, sampleI = w.y;
+                YR = (float)((double)YR + ((double)((float)sampleR * fR) - sampleI * (double)fI));
+                YI = (float)((double)YI + ((double)((float)sampleR * fI) + sampleI * (double)fR));
+                BR = (float)((double)BR + ((double)((float)sampleR * fR) + sampleI * (double)fI));
+                BI = (float)((double)BI + ((double)((float)(-sampleR) * fI) + sampleI * (double)fR));
+            }
+            const float Brot = BR * BR + BI * BI;
+            const float Yrot = YR * YR + YI * YI;
+            s_D[L] = (Brot > Yrot) ? 1 : 0;
         }
         __syncthreads();
         // ---- transition correlator, decoder.C:157-177: mask[i] * dphi[g-8+i], i ascending
@@ -473,23 +506,25 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
             }
         }
         __syncthreads();
-        // ---- arg-max once per bit period, decoder.C:202-215: csa[i] = S(g-8+i),
-        // strict '>' from -1.0 => first maximum wins
-        for (int L = tid; L < tl; L += 256) {
-            const unsigned long long g = gt + L;
-            if (g % 9 == G_CSA % 9) {
-                int max_index = -1;
-                if (g >= G_CSA) {
-                    double temp_max = -1.0;
-                    max_index = 0;
+        // ---- one word per bit period: nine window decisions + the arg-max of the
+        // timing evaluation (decoder.C:202-215: csa[i] = S(g-8+i), strict '>' from
+        // -1.0 => first maximum wins), which falls on local sample 9m+6
+        for (int M = tid; M < tl / 9; M += 256) {
+            unsigned w = 0;
 #pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        const double v = s_S[L + i];
-                        if (v > temp_max) { temp_max = v; max_index = i; }
-                    }
+            for (int k = 0; k < 9; k++) w |= (unsigned)s_D[9 * M + k] << k;
+            const int L = 9 * M + (G_CSA % 9);
+            unsigned max_index = 15;
+            if (gt + L >= G_CSA) {
+                double temp_max = -1.0;
+                max_index = 0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const double v = s_S[L + i];
+                    if (v > temp_max) { temp_max = v; max_index = i; }
                 }
-                a.argmax[(size_t)((ta + L) / 9) * a.n_slots + slot] = (signed char)max_index;
             }
+            a.words[(size_t)(ta / 9 + M) * a.n_slots + slot] = (unsigned short)(w | (max_index << 12));
         }
         __syncthreads();
         // ---- slide the histories to the front for the next tile / the next launch
@@ -504,90 +539,88 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         __syncthreads();
     }
 
-    if (tid == 0 && a.n3 > 0) { const double2 l = y3[a.n3 - 1]; st[DS_PREV] = l.x; st[DS_PREV + 1] = l.y; }
+    if (tid < 4 && a.n3 >= 4) { const double2 l = y3[a.n3 - 4 + tid]; st[DS_Y3 + 2 * tid] = l.x; st[DS_Y3 + 2 * tid + 1] = l.y; }
     if (tid < 8) { st[DS_DPHI + tid] = s_dphi[tid]; st[DS_S + tid] = s_S[tid]; }
     for (int i = tid; i < 567; i += 256) st[DS_C + i] = s_C[i];
 }
 
+// Sequential part: the timing slew limiter (decoder.C:217-249) and the bit FSM
+// (decoder.C:62-137), integers only, one lane per chain, branch-free.
+//
+// The reference's (status, burn_count, samplecount) triple only ever walks one
+// fixed path, so it is kept as a single phase counter:
+//   phase -1        STATUS_SYNCED_WAIT (or STATUS_INIT while synced == 0)
+//   phase 0, 1      the two burned samples (decoder.C:91-110; the sample that
+//                   matches the sync offset is itself the first of them)
+//   phase 2         the sample that flips to RECEIVING and is not used
+//   phase 3..7      the five accumulated samples; the decision falls on 7
+// The slew limiter's four-way branch is the rule: with diff = (argmax - prev)
+// mod 9, diff 1..4 -> prev+1, diff 5..8 -> prev-1 (same thing).
 __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
 {
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const int nc = a.n_slots;
     if (slot >= nc) return;
     if (!a.slot_active[slot]) return;
-    float *sf = a.state_f; int *si = a.state_i;
-#define SF(f) sf[(size_t)(f) * nc + slot]
+    int *si = a.state_i;
 #define SI(f) si[(size_t)(f) * nc + slot]
-    float BR = SF(0), BI = SF(1), YR = SF(2), YI = SF(3);
-    int status = SI(DI_STATUS), sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF);
-    int burn = SI(DI_BURN), samplecount = SI(DI_SAMPLECOUNT), prev_offset = SI(DI_PREV_OFFSET);
+    int synced = SI(DI_SYNCED), sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF);
+    int phase = SI(DI_PHASE), prev_offset = SI(DI_PREV_OFFSET);
 
-    const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
-    uint8_t *bits = a.bits + (size_t)slot * a.bits_cap;
+    // decoded bits are packed ('B' = 1, LSB first) and stored one 32-bit word at a
+    // time: byte stores would sit in front of every prefetched load in the in-order
+    // vmcnt queue
+    unsigned *bits = (unsigned *)(a.bits + (size_t)slot * a.bits_cap);
+    const int cap_bits = a.bits_cap * 8;
     int nbits = 0;
-    int gmod9 = (int)(a.g0 % 9);                 // g mod 9 of the current sample
-    unsigned long long g = a.g0;
-
-    for (int t = 0; t < a.n3; t++, g++) {
-        // ---- timing decision, decoder.C:202-249 (the arg-max itself is precomputed)
-        if (gmod9 == G_CSA % 9 && g >= G_CSA) {
-            int max_index = a.argmax[(size_t)(t / 9) * nc + slot];
-            if (!(prev_offset == -1 || max_index == prev_offset)) {
-                if (max_index > prev_offset) {
-                    if (max_index - prev_offset > 4) max_index = (prev_offset - 1 + 9) % 9;
-                    else                             max_index = (prev_offset + 1) % 9;
-                } else {
-                    if (prev_offset - max_index > 4) max_index = (prev_offset + 1) % 9;
-                    else                             max_index = (prev_offset - 1 + 9) % 9;
-                }
-            }
-            prev_offset = max_index;
-            const int offset = (max_index + 5) % 9;                               // decoder.C:249
-            if (status == ST_INIT) { status = ST_WAIT; sync_off = offset; }       // decoder.C:62-70
-            next_sync_off = offset;
-        }
-        // ---- mark/space decision, decoder.C:73-137; bd_seq_nbr = g + 1
-        const int bd_seq = (gmod9 + 1 == 9) ? 0 : gmod9 + 1;
-        if (++gmod9 == 9) gmod9 = 0;
-        if (status == ST_INIT) continue;
-        if (status == ST_WAIT && bd_seq == sync_off) { status = ST_BIT_START; burn = 0; }
-        if (status == ST_BIT_START) {
-            if (burn == 2) {
-                status = ST_RECEIVING; samplecount = 0;
-                BR = 0.0f; BI = 0.0f; YR = 0.0f; YI = 0.0f;
-            } else {
-                burn++;
-            }
-            continue;
-        }
-        if (status == ST_RECEIVING) {
-            float fR = 0.0f, fI = 0.0f;
+    unsigned acc = 0;
+    const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
+    const unsigned short *words = a.words + slot;
+    unsigned wq[4];
 #pragma unroll
-            for (int i = 0; i < 5; i++) if (samplecount == i) { fR = NVX_BF_R[i]; fI = NVX_BF_I[i]; }
-            const double2 s = y3[t];
-            const double sampleR = s.x, sampleI = s.y;
-            // decoder.C:115-118: float*float product, double*float product,
-            // double sum, accumulate in double, round to float
-            YR = (float)((double)YR + ((double)((float)sampleR * fR) - sampleI * (double)fI));
-            YI = (float)((double)YI + ((double)((float)sampleR * fI) + sampleI * (double)fR));
-            BR = (float)((double)BR + ((double)((float)sampleR * fR) + sampleI * (double)fI));
-            BI = (float)((double)BI + ((double)((float)(-sampleR) * fI) + sampleI * (double)fR));
-            if (++samplecount == 5) {
-                const float Brot = BR * BR + BI * BI;
-                const float Yrot = YR * YR + YI * YI;
-                if (nbits < a.bits_cap) bits[nbits] = (Brot > Yrot) ? 'B' : 'Y';
-                nbits++;
-                status = ST_WAIT;
-                sync_off = next_sync_off;
+    for (int i = 0; i < 4; i++) wq[i] = (i < periods) ? words[(size_t)i * nc] : 0;
+
+    for (int m0 = 0; m0 < periods; m0 += 4) {     // periods is a multiple of 32
+        unsigned wcur[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wcur[i] = wq[i]; if (m0 + 4 + i < periods) wq[i] = words[(size_t)(m0 + 4 + i) * nc]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned w = wcur[i];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {         // local sample 9m+k; g mod 9 == k (g0 is a multiple of 9)
+                if (k == G_CSA % 9) {
+                    // ---- timing decision, decoder.C:202-249 (arg-max precomputed; 15 = not primed yet)
+                    const int raw = (int)(w >> 12);
+                    const bool have = raw != 15;
+                    const int diff = (raw - prev_offset + 9) % 9;
+                    int mi = raw;
+                    const bool slew = (prev_offset != -1) && (diff != 0);
+                    const int up = (prev_offset + 1) % 9, dn = (prev_offset + 8) % 9;
+                    mi = slew ? ((diff <= 4) ? up : dn) : mi;
+                    const int offset = (mi + 5) % 9;                                  // decoder.C:249
+                    prev_offset = have ? mi : prev_offset;
+                    sync_off = (have && !synced) ? offset : sync_off;                 // decoder.C:62-70
+                    next_sync_off = have ? offset : next_sync_off;
+                    synced = have ? 1 : synced;
+                }
+                // ---- bit FSM, decoder.C:73-137; bd_seq_nbr mod 9 = (k + 1) mod 9
+                const bool start = (phase < 0) && synced && (((k + 1) % 9) == sync_off);
+                phase = start ? 0 : ((phase >= 0) ? phase + 1 : phase);
+                const bool decide = phase == 7;
+                acc |= decide ? (((w >> k) & 1u) << (nbits & 31)) : 0u;
+                nbits += decide ? 1 : 0;
+                if (decide && (nbits & 31) == 0) { if (nbits <= cap_bits) bits[(nbits >> 5) - 1] = acc; acc = 0; }
+                phase = decide ? -1 : phase;
+                sync_off = decide ? next_sync_off : sync_off;
             }
         }
     }
+    if ((nbits & 31) != 0 && nbits <= cap_bits) bits[nbits >> 5] = acc;
 
     a.nbits[slot] = nbits;
-    SF(0) = BR; SF(1) = BI; SF(2) = YR; SF(3) = YI;
-    SI(DI_STATUS) = status; SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off;
-    SI(DI_BURN) = burn; SI(DI_SAMPLECOUNT) = samplecount; SI(DI_PREV_OFFSET) = prev_offset;
-#undef SF
+    SI(DI_SYNCED) = synced; SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off;
+    SI(DI_PHASE) = phase; SI(DI_PREV_OFFSET) = prev_offset;
 #undef SI
 }
 
