@@ -1,0 +1,144 @@
+"""GPU tests of the drop-in boundary: the reference-shaped push surface, the
+SDRplay-shaped stream callback, the WAV file path, and the golden vectors of
+the compiled reference replayed through the HIP path (BASELINE configs 0-2)."""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+GOLD = json.loads((Path(__file__).parent / "golden" / "golden.json").read_text())
+
+
+def pad_to_frame(nv, iq):
+    pad = (-iq.shape[0]) % nv.FRAME_IN
+    return np.vstack([iq, np.zeros((pad, 2), dtype=np.int16)]) if pad else iq
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["iq"]))
+def test_reference_bits_reproduced_on_gpu(nv, name):
+    """Every golden case (clean, weak, offset, noise, silence, DC, full-scale random,
+    ragged length): the bits the compiled reference produced, bit for bit.  The tail is
+    zero-padded to a whole frame, so the GPU may decode a few extra bits after the end."""
+    rec = GOLD["iq"][name]
+    iq = cases.make_iq(nv, rec["spec"])
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=8, push_mode=True) as p:
+        p.push(0, pad_to_frame(nv, iq))
+        p.flush()
+        for tag, chain in (("518", 0), ("490", 1)):
+            want = rec[f"bits{tag}"]
+            got = p.bits(0, chain)
+            assert got[: len(want)] == want, f"{name}/{tag}"
+            assert len(got) - len(want) <= 40
+        if iq.shape[0] % nv.FRAME_IN == 0:
+            assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
+
+
+def test_wav_file_path_config0(nv, tmp_path):
+    """configs[0]/[1] plumbing: 2-channel 16-bit 252 kHz WAV -> nvx_decode_wav -> messages."""
+    rec = GOLD["iq"]["two_carrier"]
+    iq = cases.make_iq(nv, rec["spec"])
+    path = str(tmp_path / "capture.wav")
+    nv.wav_write(path, iq, nv.RATE_IN)
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True) as p:
+        frames = p.decode_wav(path)
+        assert frames == -(-iq.shape[0] // nv.FRAME_IN)
+        assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
+        assert p.bits(0, 0)[: len(rec["bits518"])] == rec["bits518"]
+    with nv.Pipeline(n_streams=1, raw_rate=True, max_frames=1, push_mode=True) as p:
+        with pytest.raises(nv.NvxError):          # wrong sample rate for this handle
+            p.decode_wav(path)
+
+
+def test_stream_callback_shape(nv):
+    """nvx_StreamACallback: planar xi/xq, jittered numSamples, cbContext = handle."""
+    rec = GOLD["iq"]["offset_490"]
+    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    xi, xq = np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])
+    rng = np.random.default_rng(9)
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=2, push_mode=True) as p:
+        pos = 0
+        while pos < xi.size:
+            m = int(min(xi.size - pos, rng.integers(1, 4096)))
+            a, b = xi[pos:pos + m].copy(), xq[pos:pos + m].copy()      # valid only during the call
+            nv.lib.nvx_StreamACallback(a.ctypes.data, b.ctypes.data, None, m, 0, p._h)
+            a[:] = 0; b[:] = 0
+            pos += m
+        p.flush()
+        assert p.bits(0, 1)[: len(rec["bits490"])] == rec["bits490"]
+        assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
+
+
+def test_unmodified_capture_loop_links_and_decodes(nv, tmp_path):
+    """The reference-shaped main program (tests/harness/capt_loop.c: capt_sched.c's ring,
+    callback and consumer loop, its own add_message) linked against libnavtex_amd.so."""
+    rec = GOLD["iq"]["two_carrier"]
+    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    data = tmp_path / "iq.bin"
+    iq.tofile(data)
+    exe = tmp_path / "capt_loop"
+    lib = ROOT / "navtex_amd"
+    subprocess.run(["gcc", "-O2", str(ROOT / "tests" / "harness" / "capt_loop.c"), "-o", str(exe), f"-L{lib}", "-lnavtex_amd",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe), str(data)], check=True, capture_output=True, text=True, timeout=300).stdout
+    got = []
+    for line in out.splitlines():
+        if "|" in line and line.split("|")[0].isdigit():
+            f, b, m = line.split("|", 2)
+            got.append([int(f), b, m.replace("\\n", "\n")])
+    assert sorted(got) == sorted(rec["messages"])
+
+
+def test_three_carriers_config2(nv, oracle):
+    """configs[2]: stream A carries 518 (+14 k) and 490 (-14 k); stream B carries the
+    4209.5 kHz service on its +14 k chain, labelled 4209 (the reference has no such label)."""
+    n_frames = 66
+    b518 = nv.sitor_encode("ZCZC EA01\nFIVE ONE EIGHT\nNNNN\n", 40)
+    b490 = nv.sitor_encode("ZCZC LB02\nFOUR NINE ZERO\nNNNN\n", 42)
+    b4209 = nv.sitor_encode("ZCZC XC03\nFOUR TWO ZERO NINE DECIMAL FIVE\nNNNN\n", 44)
+    sa = nv.make_stream([dict(freq_hz=14000, bits=b518, bit_offset=301, phase0=1), dict(freq_hz=-14000, bits=b490, bit_offset=1701, phase0=2)],
+                        seed=11, noise_amp=1200)
+    sb = nv.make_stream([dict(freq_hz=14000, bits=b4209, bit_offset=997, phase0=3)], seed=12, noise_amp=1200)
+    n = n_frames * nv.FRAME_IN
+    ia, ib = nv.synth_host(sa, nv.RATE_IN, n), nv.synth_host(sb, nv.RATE_IN, n)
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_masks=[3, 1], labels=[[518, 490], [4209, 0]], max_frames=3, push_mode=True) as p:
+        for k in range(0, n, 50000):                  # interleaved pushes of the two streams
+            p.push(0, ia[k:k + 50000]); p.push(1, ib[k:k + 50000])
+        p.flush()
+        got = sorted((s, f, b) for (s, f, b, _m) in p.messages)
+        assert got == [(0, 490, "LB02"), (0, 518, "EA01"), (1, 4209, "XC03")]
+        for s, iq, mask in ((0, ia, 3), (1, ib, 1)):
+            ref = oracle.Pipe(chain_mask=mask, charlayer=False)
+            ref.push(iq)
+            for c in range(2):
+                assert p.bits(s, c) == (ref.bits(c) if (mask >> c) & 1 else "")
+
+
+def test_launch_partitioning_is_invisible(nv):
+    """Size-independent property: one launch of 6 frames == six launches of 1 frame ==
+    2+4, on device-resident data; reset reproduces the run exactly."""
+    import signals
+    n_streams, frames = 40, 6
+    streams = [signals.stream_params(nv, 1000 + s, nv.RATE_RAW)[0] for s in range(n_streams)]
+    streams[7] = streams[3]                           # identical streams must give identical bits
+    pitch = frames * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(n_streams * pitch * 4)
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    outs = []
+    with nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=frames, char_layer=False) as p:
+        for plan in ([6], [1] * 6, [2, 4], [6]):
+            p.reset()
+            f0 = 0
+            for k in plan:
+                p.process_resident(buf, pitch, f0, k); f0 += k
+            p.fetch()
+            outs.append([p.bits(s, 0) for s in range(n_streams)])
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert outs[0][7] == outs[0][3] and len(outs[0][0]) > 100
+    buf.free()
