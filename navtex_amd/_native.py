@@ -6,11 +6,13 @@ its own and has no fallback -- if the native library is missing, import fails.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "libnavtex_amd.so"
+# NAVTEX_AMD_LIB: load another build of the same library (A/B runs of kernel variants)
+_LIB_PATH = Path(os.environ.get("NAVTEX_AMD_LIB") or (Path(__file__).resolve().parent / "libnavtex_amd.so"))
 
 OK, ERR_ARG, ERR_NODEV, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_IO, ERR_FULL = 0, -1, -2, -3, -4, -5, -6, -7
 RATE_RAW, RATE_IN = 2016000, 252000

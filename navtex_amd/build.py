@@ -30,7 +30,7 @@ CXX_SOURCES = ["nvx_api.cpp"]
 # -ffp-contract=off is part of the numerical contract: FIR products and sums are
 # rounded separately, exactly as the reference's x86-64 build does.
 COMMON = ["-O3", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+          f"-I{ROOT / 'include'}", f"-I{CSRC}"] + os.environ.get("NVX_EXTRA_CFLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "navtex_amd.h"
@@ -58,19 +59,22 @@ static int select_device(int device)
 // ------------------------------------------------------------------ handle
 static const int RESULT_SLOTS = 4;
 
+struct Message { std::string bbbb, text; int freq; };
+
 struct Slot {                          // one (stream, chain)
     bool active = false;
     int label = 0;
     std::string bits;                  // everything decoded since create/reset
     size_t polled = 0;                 // nvx_poll_bits cursor
     nvx_sitor *sitor = nullptr;
+    std::vector<Message> outbox;       // messages completed during a (possibly threaded) collect
 };
 
 struct Result {                        // one in-flight launch's bit output
     uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
     uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
     hipEvent_t done = nullptr;
-    hipEvent_t ev[3] = { nullptr, nullptr, nullptr };   // before cascade / between / after demod
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };   // cascade begin/end (stream 1), demod begin/end (stream 2)
     bool timed = false;
     bool pending = false;
 };
@@ -80,10 +84,14 @@ struct nvx_handle {
     int n_streams = 0, n_slots = 0, nch = 1;
     size_t frame_in = 0;               // complex input samples per frame at the input rate
     int y3_cap = 0, bits_cap = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // FIR cascade (or the caller's stream) and H2D staging
+    hipStream_t stream2 = nullptr;     // demodulator + D2H of the bits: overlaps the next cascade launch
+    hipEvent_t casc_done[2] = { nullptr, nullptr };   // y3[b] written
+    hipEvent_t demod_done[2] = { nullptr, nullptr };  // y3[b] consumed
+    bool demod_pending[2] = { false, false };
     // device
     uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
-    double2 *d_y3 = nullptr;
+    double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
     double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
     unsigned short *d_words = nullptr;
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
@@ -111,20 +119,28 @@ struct nvx_handle {
     uint32_t *d_in = nullptr;
 };
 
-struct SinkCtx { nvx_handle *h; int stream; };
+struct SinkCtx { nvx_handle *h; int stream; int slot; };
 
-static void sitor_sink(void *user, const char *bbbb, const char *message, int freq)
-{
-    SinkCtx *c = (SinkCtx *)user;
-    if (c->h->cfg.on_message) c->h->cfg.on_message(c->h->cfg.user, c->stream, bbbb, message, freq);
-    else add_message((char *)bbbb, (char *)message, freq);          // receiver/message_store.h:7
-}
+// The character layers of different chains run on worker threads; their messages are
+// parked per slot and handed to the user's sink afterwards, in slot order, by the
+// collecting thread (the reference calls add_message from its single DSP thread).
+static void sitor_sink(void *user, const char *bbbb, const char *message, int freq);
+
+static void deliver_outbox(nvx_handle *h, int stream, Slot &s);
 
 extern "C" __attribute__((weak, visibility("default"))) int add_message(char *bbbb, char *message, int freq)
 {
     printf("[navtex_amd] message freq=%d bbbb=%s\n%s", freq, bbbb, message);
     fflush(stdout);
     return 0;
+}
+
+static void sitor_sink_impl(nvx_handle *h, int slot, const char *bbbb, const char *message, int freq);
+
+static void sitor_sink(void *user, const char *bbbb, const char *message, int freq)
+{
+    SinkCtx *c = (SinkCtx *)user;
+    sitor_sink_impl(c->h, c->slot, bbbb, message, freq);
 }
 
 extern "C" void nvx_config_default(nvx_config *c)
@@ -140,7 +156,9 @@ static void free_handle(nvx_handle *h)
     if (!h) return;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3);
+    if (h->stream2) hipStreamSynchronize(h->stream2);
+    hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
+    for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
@@ -148,7 +166,7 @@ static void free_handle(nvx_handle *h)
         if (r.h_bits) hipHostFree(r.h_bits);
         if (r.h_nbits) hipHostFree(r.h_nbits);
         if (r.done) hipEventDestroy(r.done);
-        for (int i = 0; i < 3; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
+        for (int i = 0; i < 4; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
     }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
@@ -158,6 +176,7 @@ static void free_handle(nvx_handle *h)
         if (s.sitor) nvx_sitor_free(s.sitor);
     }
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     delete h;
 }
 
@@ -193,7 +212,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
             sl.active = (m >> c) & 1;
             sl.label = cfg->labels ? cfg->labels[2 * s + c] : (c == 0 ? 518 : 490);
             if (sl.active && cfg->char_layer) {
-                SinkCtx *ctx = new SinkCtx{ h, s };
+                SinkCtx *ctx = new SinkCtx{ h, s, 2 * s + c };
                 sink_pool().push_back(ctx);         // lives as long as the process (tiny)
                 sl.sitor = nvx_sitor_new(sl.label, sitor_sink, ctx);
             }
@@ -206,6 +225,11 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         return e_ == hipErrorOutOfMemory ? NVX_ERR_NOMEM : NVX_ERR_HIP; } } while (0)
 
     CR_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CR_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        CR_TRY(hipEventCreateWithFlags(&h->casc_done[i], hipEventDisableTiming));
+        CR_TRY(hipEventCreateWithFlags(&h->demod_done[i], hipEventDisableTiming));
+    }
     std::vector<uint8_t> active(h->n_slots);
     for (int i = 0; i < h->n_slots; i++) active[i] = h->slots[i].active;
     CR_TRY(hipMalloc(&h->d_masks, h->n_streams));
@@ -213,7 +237,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_masks, h->masks.data(), h->n_streams, hipMemcpyHostToDevice));
     CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
     CR_TRY(hipMalloc(&h->d_cstate, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
-    CR_TRY(hipMalloc(&h->d_y3, (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
+    for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
     CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
     CR_TRY(hipMalloc(&h->d_words, (size_t)(h->y3_cap / 9) * h->n_slots * sizeof(unsigned short)));
@@ -226,7 +250,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipHostMalloc((void **)&r.h_bits, (size_t)h->n_slots * h->bits_cap, hipHostMallocDefault));
         CR_TRY(hipHostMalloc((void **)&r.h_nbits, (size_t)h->n_slots * sizeof(int), hipHostMallocDefault));
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        for (int i = 0; i < 3; i++) CR_TRY(hipEventCreate(&r.ev[i]));
+        for (int i = 0; i < 4; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
     if (cfg->push_mode) {
         h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
@@ -252,9 +276,11 @@ extern "C" int nvx_reset(nvx_handle *h)
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream2));
     for (auto &r : h->res) r.pending = false;
     h->collected = h->launched;
     h->g0 = 0;
+    h->demod_pending[0] = h->demod_pending[1] = false;
     HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
@@ -278,27 +304,41 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     Result &r = h->res[h->launched % RESULT_SLOTS];
     if (r.pending) { int rc = collect_locked(h); if (rc != NVX_OK) return rc; }
 
+    const int yb = (int)(h->launched & 1);              // y3 buffer of this launch
+    // Measured (profiles/r01, DESIGN.md tuning log): running the demodulator on a second
+    // stream beside the NEXT cascade launch loses -- the persistent cascade grid owns every
+    // CU's LDS, so the demod workgroups only become resident as it drains.  Default: same stream.
+    static const bool overlap = getenv("NVX_OVERLAP") && atoi(getenv("NVX_OVERLAP")) == 1;
+    hipStream_t s2 = overlap ? h->stream2 : st;
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
-    ca.state = h->d_cstate; ca.y3 = h->d_y3; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    ca.state = h->d_cstate; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     nvx_demod_args da{};
-    da.y3 = h->d_y3; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
+    da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
     da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.words = h->d_words;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
 
+    // cascade on `st`: it may not overwrite y3[yb] before the demodulator of two launches ago has read it
+    if (h->demod_pending[yb]) HIP_TRY(hipStreamWaitEvent(st, h->demod_done[yb], 0));
     r.timed = h->timing;
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[0], st));
     HIP_TRY(nvx_launch_cascade(&ca, h->cfg.raw_rate, h->nch, st));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
-    HIP_TRY(nvx_launch_demod(&da, st));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], st));
     HIP_TRY(hipMemcpyAsync(h->h_status + (h->launched % RESULT_SLOTS), h->d_ctrl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(r.done, st));
+    HIP_TRY(hipEventRecord(h->casc_done[yb], st));
+    // demodulator + bit download on the second stream, behind this cascade only
+    HIP_TRY(hipStreamWaitEvent(s2, h->casc_done[yb], 0));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], s2));
+    HIP_TRY(nvx_launch_demod(&da, s2));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], s2));
+    HIP_TRY(hipEventRecord(h->demod_done[yb], s2));
+    h->demod_pending[yb] = true;
+    HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, s2));
+    HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, s2));
+    HIP_TRY(hipEventRecord(r.done, s2));
     r.pending = true;
     h->launched++;
     h->last_n3 = da.n3;
@@ -319,25 +359,58 @@ static int collect_locked(nvx_handle *h)
             }
             if (r.timed) {
                 HIP_TRY(hipEventElapsedTime(&h->ms[0], r.ev[0], r.ev[1]));
-                HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[1], r.ev[2]));
+                HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[2], r.ev[3]));
                 h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
             }
-            for (int i = 0; i < h->n_slots; i++) {
-                Slot &s = h->slots[i];
-                if (!s.active) continue;
-                int n = r.h_nbits[i];
-                if (n > h->bits_cap * 8) { nvx_set_error("bit buffer overflow on slot %d (%d > %d)", i, n, h->bits_cap * 8); return NVX_ERR_STATE; }
-                const uint32_t *pw = (const uint32_t *)(r.h_bits + (size_t)i * h->bits_cap);
-                const size_t at = s.bits.size();
-                s.bits.resize(at + (size_t)n);
-                for (int k = 0; k < n; k++) s.bits[at + k] = ((pw[k >> 5] >> (k & 31)) & 1u) ? 'B' : 'Y';
-                if (s.sitor) nvx_sitor_receive_bits(s.sitor, s.bits.data() + at, (size_t)n);
+            int bad_slot = -1;
+            auto work = [&](int lo, int hi) {
+                for (int i = lo; i < hi; i++) {
+                    Slot &s = h->slots[i];
+                    if (!s.active) continue;
+                    int n = r.h_nbits[i];
+                    if (n > h->bits_cap * 8) { bad_slot = i; continue; }
+                    const uint32_t *pw = (const uint32_t *)(r.h_bits + (size_t)i * h->bits_cap);
+                    const size_t at = s.bits.size();
+                    s.bits.resize(at + (size_t)n);
+                    for (int k = 0; k < n; k++) s.bits[at + k] = ((pw[k >> 5] >> (k & 31)) & 1u) ? 'B' : 'Y';
+                    if (s.sitor) nvx_sitor_receive_bits(s.sitor, s.bits.data() + at, (size_t)n);
+                }
+            };
+            static const int host_threads = [] {
+                const char *e = getenv("NVX_HOST_THREADS");
+                int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+                return n < 1 ? 1 : (n > 16 ? 16 : n);
+            }();
+            const int nt = (h->n_slots >= 256 && h->cfg.char_layer) ? host_threads : 1;
+            if (nt > 1) {
+                std::vector<std::thread> pool;
+                const int per = (h->n_slots + nt - 1) / nt;
+                for (int t = 0; t < nt; t++) pool.emplace_back(work, t * per, std::min(h->n_slots, (t + 1) * per));
+                for (auto &t : pool) t.join();
+            } else {
+                work(0, h->n_slots);
             }
+            if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot); return NVX_ERR_STATE; }
+            for (int i = 0; i < h->n_slots; i++) if (!h->slots[i].outbox.empty()) deliver_outbox(h, i / 2, h->slots[i]);
             r.pending = false;
         }
         h->collected++;
     }
     return NVX_OK;
+}
+
+static void sitor_sink_impl(nvx_handle *h, int slot, const char *bbbb, const char *message, int freq)
+{
+    h->slots[slot].outbox.push_back(Message{ bbbb, message, freq });
+}
+
+static void deliver_outbox(nvx_handle *h, int stream, Slot &s)
+{
+    for (auto &m : s.outbox) {
+        if (h->cfg.on_message) h->cfg.on_message(h->cfg.user, stream, m.bbbb.c_str(), m.text.c_str(), m.freq);
+        else add_message((char *)m.bbbb.c_str(), (char *)m.text.c_str(), m.freq);      // receiver/message_store.h:7
+    }
+    s.outbox.clear();
 }
 
 extern "C" int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_frame, int n_frames, void *hip_stream)
@@ -405,7 +478,7 @@ extern "C" size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     size_t n = std::min(cap_pairs, (size_t)h->last_n3);
-    if (hipMemcpy(out, h->d_y3 + (size_t)(2 * stream + chain) * h->y3_cap, n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hipMemcpy(out, h->d_y3[(h->launched + 1) & 1] + (size_t)(2 * stream + chain) * h->y3_cap, n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
 

@@ -65,9 +65,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vect
 #define XS 74
 #define X_ENTRIES (4 * XS)
 #define U_ENTRIES 336
-#define Y2_ENTRIES 264
 #define U_RUN 224
-#define Y2_RUN 160
+#ifndef NVX_Y2_RUN
+#define NVX_Y2_RUN 160                    /* FIR2 outputs per FIR3 run: 160 (16 outputs) or 80 (8 outputs) */
+#endif
+#define Y2_RUN NVX_Y2_RUN
+#define Y3_PER_RUN (Y2_RUN / 10)
+#define Y2_ENTRIES (((70 + Y2_RUN + 31) + 7) / 8 * 8)
 
 template <int NCH>
 struct CascadeLds {
@@ -316,12 +320,12 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                     for (int c = 0; c < NCH; c++) {
                         if (NCH == 2 && !((mask >> c) & 1u)) continue;
                         const int ch = (NCH == 1) ? chain_of_slot0 : c;
-                        const int p = half & 15;
+                        const int p = half & (Y3_PER_RUN - 1);
                         const double *yb = (const double *)&lds.Y2[c][10 * p] + comp;
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
-                        if (lane < 32) {
+                        if (lane < 2 * Y3_PER_RUN) {
                             double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + p));
                             out[comp] = acc;
                         }
@@ -331,14 +335,14 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         double2 t0 = lds.Y2[c][Y2_RUN + lane];
-                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 40) ? lane : 39)];
+                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36)];   // keep3 - 64 <= 37
                         NVX_WAVE_LDS_FENCE();
                         if (lane < keep3) lds.Y2[c][lane] = t0;
                         if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
                     }
                     NVX_WAVE_LDS_FENCE();
                     n_y2 -= Y2_RUN;
-                    n3_done += 16;
+                    n3_done += Y3_PER_RUN;
                 }
             }
         };
