@@ -142,3 +142,62 @@ def test_launch_partitioning_is_invisible(nv):
     assert outs[0] == outs[1] == outs[2] == outs[3]
     assert outs[0][7] == outs[0][3] and len(outs[0][0]) > 100
     buf.free()
+
+
+def test_callback_from_a_producer_thread_while_polling(nv, oracle):
+    """SURVEY 8(f) rank 1 in miniature: a 'vendor' thread delivers jittered callbacks while
+    the consumer thread polls bits -- the library's locking must keep the stream intact."""
+    import threading
+    import signals
+    st, _ = signals.stream_params(nv, 77, nv.RATE_IN)
+    n = 30 * nv.FRAME_IN
+    iq = nv.synth_host(st, nv.RATE_IN, n)
+    xi, xq = np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True) as p:
+        def producer():
+            rng = np.random.default_rng(5)
+            pos = 0
+            while pos < n:
+                m = int(min(n - pos, rng.integers(200, 5000)))
+                nv.lib.nvx_StreamACallback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, p._h)
+                pos += m
+        t = threading.Thread(target=producer)
+        t.start()
+        seen = ""
+        while t.is_alive():
+            seen = p.bits(0, 0)                       # concurrent nvx_poll_bits
+        t.join()
+        p.flush()
+        ref = oracle.Pipe(chain_mask=1, charlayer=False)
+        ref.push(iq)
+        assert p.bits(0, 0) == ref.bits(0) and ref.bits(0).startswith(seen)
+
+
+def test_error_paths(nv):
+    import signals
+    with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=1, push_mode=False) as p:
+        with pytest.raises(nv.NvxError) as e:
+            p.push(0, np.zeros((16, 2), dtype=np.int16))
+        assert e.value.code == -5                      # NVX_ERR_STATE: not a push-mode handle
+        buf = nv.DeviceBuffer(2 * nv.FRAME_IN * 4 * 2)
+        with pytest.raises(nv.NvxError) as e:
+            p.process_resident(buf, 2 * nv.FRAME_IN, 0, 2)      # n_frames > max_frames
+        assert e.value.code == -1
+        with pytest.raises(nv.NvxError) as e:
+            p.process_resident(buf, 2 * nv.FRAME_IN + 2, 0, 1)  # pitch not a multiple of 4
+        assert e.value.code == -1
+        buf.free()
+    with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=1, push_mode=True) as p:
+        blk = np.zeros((nv.FRAME_IN, 2), dtype=np.int16)
+        p.push(0, blk); p.push(0, blk)                 # staging holds max_frames + 1 frames per stream
+        with pytest.raises(nv.NvxError) as e:
+            p.push(0, blk)                              # stream 1 never delivered: stream 0 may not run further ahead
+        assert e.value.code == -7                      # NVX_ERR_FULL
+        p.push(1, blk); p.push(1, blk)                 # the lagging stream catches up -> launches happen
+        p.push(0, blk)
+        p.flush()
+        assert p.bit_count(0, 0) == p.bit_count(1, 0)
+    with pytest.raises(nv.NvxError):
+        nv.Pipeline(n_streams=1, chain_mask=0)
+    with pytest.raises(nv.NvxError):
+        nv.Pipeline(n_streams=1, device=99)

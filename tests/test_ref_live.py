@@ -1,0 +1,77 @@
+"""Oracle and product host code against the LIVE compiled reference
+(oracle/_ref/ref_*), on fresh random cases beyond the committed goldens.
+Only runs where the reference seams were built (the build container);
+skipped on the GPU box, where /root/reference does not exist."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.skipif(not ob.have_ref(), reason="compiled reference (oracle/_ref) not present")
+
+
+def u64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_fir_seams_random_iq(oracle, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(30000, 90000))
+    iq = rng.integers(-32768, 32768, size=(n, 2), dtype=np.int16)
+    data = iq.tobytes()
+    y1 = oracle.fir1(iq)
+    assert np.array_equal(u64(y1), np.frombuffer(ob.run_ref("fir1", data)["y1"], dtype=np.uint64).reshape(-1, 2))
+    f2, f3 = ob.run_ref("fir2", data), ob.run_ref("fir3", data)
+    for chain, tag in ((0, "518"), (1, "490")):
+        y2 = oracle.fir2(oracle.mix(y1, chain))
+        assert np.array_equal(u64(y2).reshape(-1), np.frombuffer(f2[f"y2_{tag}"], dtype=np.uint64))
+        y3 = oracle.fir3(y2)
+        assert np.array_equal(u64(y3).reshape(-1), np.frombuffer(f3[f"y3_{tag}"], dtype=np.uint64))
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_full_path_random_signal(nv, oracle, seed):
+    import signals
+    rng = np.random.default_rng(seed)
+    st, _ = signals.stream_params(nv, 500 + seed, nv.RATE_IN, freq_hz=int(rng.choice([14000, -14000])) + int(rng.integers(-15, 16)),
+                                  noise_amp=int(rng.integers(500, 6000)), amplitude=int(rng.integers(2000, 12000)), n_phasing=30)
+    iq = nv.synth_host(st, nv.RATE_IN, 252000 * 18 + int(rng.integers(0, 5000)))
+    data = iq.tobytes()
+    bits = ob.run_ref("bits", data)
+    full = ob.run_ref("full", data)
+    p = oracle.Pipe(chain_mask=3)
+    p.push(iq)
+    assert p.bits(0) == bits["bits518"].decode() and p.bits(1) == bits["bits490"].decode()
+    assert [tuple(m) for m in p.messages] == [tuple(m) for m in ob.parse_messages(full["messages"])]
+    # product character layer on the reference's own bits
+    got = []
+    for tag, freq in (("bits518", 518), ("bits490", 490)):
+        s = nv.Sitor(freq); s.feed(bits[tag].decode()); got += s.messages
+    assert sorted(got) == sorted(tuple(m) for m in ob.parse_messages(full["messages"]))
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_character_layer_random_bits_and_flips(nv, oracle, seed):
+    """Random garbage and randomly damaged traffic: messages and full trace, reference vs both implementations."""
+    rng = np.random.default_rng(seed)
+    text = "ZCZC " + "".join(rng.choice(list("ABCDEFGH"), 2)) + f"{int(rng.integers(0, 100)):02d}\n" + \
+           "".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZ 0123456789.,/-"), 200)) + "\nNNNN\n"
+    bits = list(nv.sitor_encode(text, 25))
+    for k in rng.integers(0, len(bits), size=int(len(bits) * rng.choice([0.0, 0.005, 0.03]))):
+        bits[k] = "B" if bits[k] == "Y" else "Y"
+    bits = "".join(bits) + "".join(rng.choice(["B", "Y"], 3000))
+    r = ob.run_ref("sm", bits.encode())
+    want_msgs, want_trace = [tuple(m) for m in ob.parse_messages(r["messages"])], r["stdout"].decode("latin1")
+    o = oracle.CharLayer(518); o.feed(bits)
+    assert o.messages == want_msgs and o.trace() == want_trace
+    s = nv.Sitor(518, trace=True); s.feed(bits)
+    assert s.messages == want_msgs and s.trace() == want_trace
+
+
+def test_decoder_random_inputs(oracle):
+    rng = np.random.default_rng(77)
+    y3 = rng.normal(size=(6000, 2)) * 3000.0
+    r = ob.run_ref("dec", np.ascontiguousarray(y3).tobytes())
+    bits, _ = oracle.decode(y3)
+    assert bits == r["bits518"].decode() and len(bits) > 500
