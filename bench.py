@@ -60,18 +60,24 @@ def main():
 
     import torch
     dist = None
+    # NVX_BENCH_BACKEND=gloo / NVX_BENCH_DEVICE=<n>: rehearsal of the multi-process path on a box
+    # with fewer GPUs than ranks (RCCL refuses two ranks on one device); never used by the driver.
+    backend = os.environ.get("NVX_BENCH_BACKEND", "nccl")
+    device = int(os.environ.get("NVX_BENCH_DEVICE", local))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import navtex_amd as nv
     import signals
 
     if nv.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
-    device = local
     S, F = args.streams, args.frames
     n_per_stream = F * nv.FRAME_RAW
     pitch = n_per_stream + args.pitch_pad
@@ -161,7 +167,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -113,3 +113,47 @@ def test_many_streams_single_chain(nv, oracle):
             assert p.bits(s, c) == ref.bits(c), f"stream {s}"
             assert p.bits(s, 1 - c) == ""
     buf.free()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_randomized_configurations(nv, oracle, seed):
+    """Random stream counts, chain masks (1, 2, 3 mixed -> both kernel instantiations), input rate,
+    carrier offsets/levels and launch partitions; every chain of every stream against the oracle."""
+    rng = np.random.default_rng(seed)
+    raw = bool(rng.integers(0, 2))
+    rate = nv.RATE_RAW if raw else nv.RATE_IN
+    frame = nv.FRAME_RAW if raw else nv.FRAME_IN
+    n_streams = int(rng.integers(1, 40 if raw else 70))
+    n_frames = int(rng.integers(3, 6 if raw else 12))
+    masks = [int(rng.choice([1, 2, 3])) for _ in range(n_streams)]
+    if seed % 2:
+        masks = [m if m != 3 else 1 for m in masks]            # exercise the single-chain kernel too
+    spb = rate // 100
+    iqs = []
+    for s in range(n_streams):
+        carriers = []
+        for c, f in ((0, 14000), (1, -14000)):
+            if (masks[s] >> c) & 1 or rng.random() < 0.3:       # sometimes a carrier nobody decodes
+                carriers.append(dict(freq_hz=f + int(rng.integers(-10, 11)), bits=nv.sitor_encode(signals.stream_text(100 * seed + s), 8),
+                                     bit_offset=int(rng.integers(0, spb)), phase0=int(rng.integers(0, 2**32)),
+                                     amplitude=int(rng.integers(1500, 9000))))
+        st = nv.make_stream(carriers, seed=1000 * seed + s, noise_amp=int(rng.integers(0, 4000)))
+        iqs.append(nv.synth_host(st, rate, n_frames * frame))
+    pitch = n_frames * frame + 4 * int(rng.integers(0, 64))
+    buf = nv.DeviceBuffer(n_streams * pitch * 4)
+    for s in range(n_streams):
+        buf.upload(iqs[s], offset=s * pitch * 4)
+    max_frames = int(rng.integers(1, n_frames + 1))
+    with nv.Pipeline(n_streams=n_streams, raw_rate=raw, chain_masks=masks, max_frames=max_frames, char_layer=False) as p:
+        f0 = 0
+        while f0 < n_frames:
+            k = int(min(n_frames - f0, rng.integers(1, max_frames + 1)))
+            p.process_resident(buf, pitch, f0, k); f0 += k
+        p.fetch()
+        for s in range(n_streams):
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
+            (ref.push_raw if raw else ref.push)(iqs[s])
+            for c in range(2):
+                want = ref.bits(c) if (masks[s] >> c) & 1 else ""
+                assert p.bits(s, c) == want, f"seed {seed} stream {s} chain {c} mask {masks[s]} raw {raw}"
+    buf.free()
