@@ -91,6 +91,33 @@ NVX_API void nvx_StreamACallback(short *xi, short *xq, void *params,
                                  unsigned int numSamples, unsigned int reset, void *cbContext);
 
 /* ==========================================================================
+ * B'. Live-capture ring: the producer/consumer structure of the reference's
+ *    capture thread (receiver/capt_sched.c:105-148 producer, :443-446 ring,
+ *    :484-528 consumer loop) inside the library, for callers that must never
+ *    block in the vendor callback.
+ *      producer  nvx_capture_callback(): StreamACallback's shape, cbContext =
+ *                the nvx_capture*; copies xi/xq into an interleaved int16 ring
+ *                and returns.  If the ring has no room the excess samples are
+ *                DROPPED and counted (the reference's ring silently overwrites
+ *                unread data instead, capt_sched.c:120-129).
+ *      consumer  a library thread that wakes on new data (the reference polls
+ *                every 50 ms), splits wrapped spans exactly like :494-503 and
+ *                feeds nvx_push_iq().
+ * ========================================================================== */
+typedef struct nvx_capture nvx_capture;
+/* h must be a push-mode handle; the forward declaration of nvx_handle is below */
+struct nvx_handle;
+NVX_API int  nvx_capture_start(struct nvx_handle *h, int stream, double ring_seconds, nvx_capture **out);
+NVX_API void nvx_capture_callback(short *xi, short *xq, void *params, unsigned int numSamples,
+                                  unsigned int reset, void *cbContext);
+/* drains the ring, stops the consumer thread, flushes the handle */
+NVX_API int  nvx_capture_stop(nvx_capture *c);
+/* complex samples offered by the producer / dropped on overrun / handed to the GPU pipeline */
+NVX_API void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed);
+/* test hook: pause (1) / resume (0) the consumer, to provoke an overrun deterministically */
+NVX_API void nvx_capture_pause(nvx_capture *c, int paused);
+
+/* ==========================================================================
  * C. Block API (what A and B adapt onto).
  * ========================================================================== */
 typedef struct nvx_handle nvx_handle;
