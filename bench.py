@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-charlayer", action="store_true")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra complex samples between streams (multiple of 4)")
+    ap.add_argument("--variant-a", action="store_true",
+                    help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
+                         "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
     return ap.parse_args()
 
 
@@ -79,7 +82,9 @@ def main():
     if nv.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
     S, F = args.streams, args.frames
-    n_per_stream = F * nv.FRAME_RAW
+    raw = not args.variant_a
+    RATE, FRAME = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)
+    n_per_stream = F * FRAME
     pitch = n_per_stream + args.pitch_pad
     samples_per_step = S * n_per_stream
     bytes_per_step = samples_per_step * BYTES_PER_SAMPLE
@@ -89,13 +94,13 @@ def main():
     streams = []
     for s in range(S):
         gid = rank * S + s                                     # global stream id: subsets per GPU
-        st, _ = signals.stream_params(nv, gid, nv.RATE_RAW)
+        st, _ = signals.stream_params(nv, gid, RATE)
         streams.append(st)
     buf = nv.DeviceBuffer(S * pitch * BYTES_PER_SAMPLE, device=device)
-    nv.synth_device(streams, nv.RATE_RAW, n_per_stream, buf, pitch)
+    nv.synth_device(streams, RATE, n_per_stream, buf, pitch)
     t_gen = time.time() - t0
 
-    pipe = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F,
+    pipe = nv.Pipeline(n_streams=S, raw_rate=raw, chain_mask=nv.CHAIN_518, max_frames=F,
                        char_layer=not args.no_charlayer, device=device)
 
     def sync_all():
@@ -114,27 +119,27 @@ def main():
         n_cs = min(args.cpu_streams or 2 * ncpu, S)
         cf = F                         # whole batch length: every cascade dispatch of this run has the same shape
         # the sample = the first cf frames of the first n_cs streams, copied back from HBM
-        sample = np.empty((n_cs, cf * nv.FRAME_RAW, 2), dtype=np.int16)
+        sample = np.empty((n_cs, cf * FRAME, 2), dtype=np.int16)
         for s in range(n_cs):
-            sample[s] = buf.download(cf * nv.FRAME_RAW * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+            sample[s] = buf.download(cf * FRAME * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
         # GPU bits for the same frames, from reset state
         pipe.process_resident(buf, pitch, 0, cf)
         pipe.fetch()
         gpu_bits = [pipe.bits(s, 0) for s in range(n_cs)]
         if not args.no_cpu and world == 1:
             n252 = cf * nv.FRAME_IN
-            per_pass = n_cs * cf * nv.FRAME_RAW
+            per_pass = n_cs * cf * FRAME
             # calibrate, then size the repeat count for ~6 s wall on all threads (~100 core-seconds
             # at 16 threads would exceed the "few minutes" budget; this is ~6 s x ncpu core-seconds)
-            sN, cpu_bits = ob.bench(sample, n_cs, n252, True, 1, ncpu, want_bits=True)
+            sN, cpu_bits = ob.bench(sample, n_cs, n252, raw, 1, ncpu, want_bits=True)
             rep = max(1, int(6.0 / max(sN, 1e-3)))
-            sN = ob.bench(sample, n_cs, n252, True, 1, ncpu, repeat=rep)[0]
+            sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu, repeat=rep)[0]
             one = min(n_cs, 2)
-            s1 = ob.bench(sample[:one], one, n252, True, 1, 1, repeat=max(1, rep // 8))[0]
+            s1 = ob.bench(sample[:one], one, n252, raw, 1, 1, repeat=max(1, rep // 8))[0]
             cpu = {
                 "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
                 "cores": ncpu, "kind": "port",
-                "value_1thread": round(one * cf * nv.FRAME_RAW * max(1, rep // 8) / s1 / 1e6, 2),
+                "value_1thread": round(one * cf * FRAME * max(1, rep // 8) / s1 / 1e6, 2),
                 "sample": f"all {cf} frames of the first {n_cs} streams of the bench batch ({per_pass / 1e6:.0f} M raw samples), "
                           f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
                 "seconds": round(sN, 2),
@@ -143,7 +148,7 @@ def main():
             cpu_bits = []
             for s in range(n_cs if world == 1 else min(n_cs, 4)):
                 o = ob.Pipe(chain_mask=1, charlayer=False)
-                o.push_raw(sample[s])
+                (o.push_raw if raw else o.push)(sample[s])
                 cpu_bits.append(o.bits(0))
         parity = all(g == c for g, c in zip(gpu_bits, cpu_bits)) and len(cpu_bits) > 0 and all(len(c) > 0 for c in cpu_bits)
         if not parity:
@@ -185,7 +190,7 @@ def main():
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text())
-                if rec.get("streams") == S and rec.get("frames") == F:
+                if raw and rec.get("streams") == S and rec.get("frames") == F:
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
@@ -193,12 +198,14 @@ def main():
             "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(value, 1), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, "
-                                   f"{F} frames ({F * 0.32:.2f} s) resident in HBM (BASELINE configs[3]; x{world} GPUs = configs[4] shape)",
+            "config": {"workload": (f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, "
+                                    f"{F} frames ({F * 0.32:.2f} s) resident in HBM (BASELINE configs[3]; x{world} GPUs = configs[4] shape)") if raw else
+                                   (f"VARIANT A (not the headline): {S} channels x 252 kS/s int16 IQ per GPU, {F} frames ({F * 0.32:.2f} s), "
+                                    f"no stage 0 -- fp64-issue-bound by design (SURVEY 7-2)"),
                        "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step,
-                       "stage0": "integrate-and-dump /8 (build-owned)", "chains_per_stream": 1,
+                       "stage0": "integrate-and-dump /8 (build-owned)" if raw else "none", "chains_per_stream": 1,
                        "parallelism": f"streams sharded {world} ways, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>" if raw else "nvx_fir_cascade<252k,1>", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_step,
                          "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),

@@ -157,3 +157,24 @@ def test_randomized_configurations(nv, oracle, seed):
                 want = ref.bits(c) if (masks[s] >> c) & 1 else ""
                 assert p.bits(s, c) == want, f"seed {seed} stream {s} chain {c} mask {masks[s]} raw {raw}"
     buf.free()
+
+
+def test_long_run_state_carry(nv, oracle):
+    """100 s of signal through ~105 launches of 1-3 frames: FIR histories, the 567-deep
+    correlation window, the sample counter g0 and the character layer never drift."""
+    text = "ZCZC LR01\n" + "".join(f"LONG RUN LINE {i:02d} 0123456789\n" for i in range(12)) + "NNNN\n"
+    bits_tx = nv.sitor_encode(text, 40)
+    st = nv.make_stream([dict(freq_hz=14000, bits=bits_tx, bit_offset=1111, phase0=99)], seed=321, noise_amp=2500)
+    n = 313 * nv.FRAME_IN                               # 100.2 s
+    iq = nv.synth_host(st, nv.RATE_IN, n)
+    ref = oracle.Pipe(chain_mask=1)
+    ref.push(iq)
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=3, push_mode=True) as p:
+        rng = np.random.default_rng(0)
+        pos = 0
+        while pos < n:
+            m = int(min(n - pos, rng.integers(10000, 250000)))
+            p.push(0, iq[pos:pos + m]); pos += m
+        p.flush()
+        assert p.bits(0, 0) == ref.bits(0) and len(ref.bits(0)) > 9900
+        assert [(f, b, m) for (_s, f, b, m) in p.messages] == ref.messages and len(ref.messages) >= 1
