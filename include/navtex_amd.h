@@ -277,6 +277,24 @@ NVX_API int nvx_synth_host(const nvx_synth_stream *s, uint32_t sample_rate,
 NVX_API int nvx_synth_device(int device, const nvx_synth_stream *streams, int n_streams,
                              uint32_t sample_rate, size_t n, void *d_out, size_t pitch_samples);
 
+/* ==========================================================================
+ * G. Wideband front-end (no reference counterpart: the reference tunes ONE 252 kS/s
+ *    slice, receiver/capt_sched.c:356-417).  An 8-channel polyphase
+ *    channeliser in integer arithmetic: one 2.016 MS/s stream -> eight 252 kS/s
+ *    sub-bands centred at k * 252 kHz (k = 4..7 are the negative frequencies), each a
+ *    valid input stream of a raw_rate = 0 handle (two NAVTEX chains at +-14 kHz per
+ *    sub-band -> up to 16 carriers per wideband stream).
+ *    d_raw: [n_wide][pitch_raw] packed IQ; n_out outputs per sub-band (multiple of 64)
+ *    are produced from the 8*n_out raw samples starting at first_sample;
+ *    d_sub: [n_wide*8][pitch_sub], written from column sub_first.
+ *    d_hist_in / d_hist_out: [n_wide][40] packed raw samples carried between calls
+ *    (NULL in = silence before the first sample; NULL out = not saved; in != out).
+ * ========================================================================== */
+#define NVX_WB_SUBBANDS 8
+NVX_API int nvx_channelise_resident(int device, const void *d_raw, size_t pitch_raw, size_t first_sample,
+                                    int n_wide, size_t n_out, const void *d_hist_in, void *d_hist_out,
+                                    void *d_sub, size_t pitch_sub, size_t sub_first, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRA
                       NvxError, lib)
 
 __all__ = ["Pipeline", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
-           "DeviceBuffer", "wav_write", "wav_read", "NvxError", "lib",
+           "DeviceBuffer", "channelise", "wav_write", "wav_read", "NvxError", "lib",
            "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
 
 
@@ -118,6 +118,15 @@ def synth_device(streams: Sequence[N.SynthStream], rate: int, n: int, buf: Devic
     arr = (N.SynthStream * len(streams))(*streams)
     arr._keep = list(streams)
     N.check(lib.nvx_synth_device(buf.device, arr, len(streams), rate, n, buf.ptr, pitch), "nvx_synth_device")
+
+
+def channelise(raw: "DeviceBuffer", pitch_raw: int, first_sample: int, n_wide: int, n_out: int, sub: "DeviceBuffer", pitch_sub: int,
+               sub_first: int = 0, hist_in: Optional["DeviceBuffer"] = None, hist_out: Optional["DeviceBuffer"] = None) -> None:
+    """Wideband front-end (nvx_channelise_resident): n_wide streams at 2.016 MS/s -> 8*n_wide sub-bands at 252 kS/s."""
+    N.check(lib.nvx_channelise_resident(raw.device, raw.ptr, pitch_raw, first_sample, n_wide, n_out,
+                                        hist_in.ptr if hist_in else None, hist_out.ptr if hist_out else None,
+                                        sub.ptr, pitch_sub, sub_first, None), "nvx_channelise_resident")
+    N.check(lib.nvx_device_sync(raw.device), "nvx_device_sync")
 
 
 # ------------------------------------------------------------------ pipeline

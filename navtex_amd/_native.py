@@ -83,6 +83,7 @@ def _load() -> C.CDLL:
         "nvx_synth_host": (i, [C.POINTER(SynthStream), u32, C.c_uint64, sz, vp]),
         "nvx_synth_device": (i, [i, C.POINTER(SynthStream), i, u32, sz, vp, sz]),
         "nvx_atan2_host": (C.c_double, [C.c_double, C.c_double]),
+        "nvx_channelise_resident": (i, [i, vp, sz, sz, i, sz, vp, vp, vp, sz, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

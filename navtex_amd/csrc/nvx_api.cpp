@@ -649,6 +649,30 @@ extern "C" int nvx_synth_device(int device, const nvx_synth_stream *streams, int
     return NVX_OK;
 }
 
+// ------------------------------------------------------------ wideband front-end
+extern "C" int nvx_channelise_resident(int device, const void *d_raw, size_t pitch_raw, size_t first_sample, int n_wide,
+                                       size_t n_out, const void *d_hist_in, void *d_hist_out, void *d_sub, size_t pitch_sub,
+                                       size_t sub_first, void *hip_stream)
+{
+    if (!d_raw || !d_sub || n_wide < 1 || n_out == 0 || (n_out % 64) || (pitch_raw & 3) || (first_sample & 3) ||
+        (d_hist_in && d_hist_in == d_hist_out)) {
+        nvx_set_error("nvx_channelise_resident: bad argument (n_out must be a multiple of 64, pitches/offsets of 4)");
+        return NVX_ERR_ARG;
+    }
+    int rc = select_device(device); if (rc != NVX_OK) return rc;
+    nvx_channelise_args a{};
+    a.raw = (const uint32_t *)d_raw; a.pitch_raw = pitch_raw; a.first_sample = first_sample; a.n_wide = n_wide; a.n_out = n_out;
+    a.hist_in = (const uint32_t *)d_hist_in; a.hist_out = (uint32_t *)d_hist_out;
+    a.sub = (uint32_t *)d_sub; a.pitch_sub = pitch_sub; a.sub_first = sub_first;
+    // enough blocks to fill the chip several times over, long enough spans to amortise the 40-sample halo
+    const size_t n_chunks = n_out / 64;
+    size_t cpb = (n_chunks * (size_t)n_wide + 16383) / 16384;
+    if (cpb < 8) cpb = 8;
+    a.chunks_per_block = (int)std::min<size_t>(cpb, n_chunks);
+    HIP_TRY(nvx_launch_channelise(&a, (hipStream_t)hip_stream));
+    return NVX_OK;
+}
+
 // ------------------------------------------------------------------ WAV path
 extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
 {

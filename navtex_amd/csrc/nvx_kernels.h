@@ -53,9 +53,22 @@ typedef struct {
     uint32_t *out; size_t pitch; size_t n; uint32_t spb;
 } nvx_synth_args;
 
+typedef struct {
+    const uint32_t *raw;       /* [n_wide][pitch_raw] packed IQ at 2.016 MS/s                 */
+    size_t pitch_raw, first_sample;
+    int n_wide;
+    size_t n_out;              /* outputs per sub-band in this launch (multiple of 64)         */
+    const uint32_t *hist_in;   /* [n_wide][40] raw words preceding first_sample, or NULL (= 0) */
+    uint32_t *hist_out;        /* [n_wide][40] last raw words of this launch, or NULL          */
+    uint32_t *sub;             /* [n_wide*8][pitch_sub] packed IQ at 252 kS/s                  */
+    size_t pitch_sub, sub_first;
+    int chunks_per_block;
+} nvx_channelise_args;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStream_t s);
 hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s);
 hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s);
 hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s);

@@ -48,6 +48,58 @@ void nvxo_stage0(const int16_t *raw, size_t n_out, int16_t *out)
 }
 
 /* ========================================================================== */
+/* wideband channeliser (build-owned, no reference counterpart)               */
+/* ========================================================================== */
+#define NVXO_PFB_TABLE static const
+#include "nvx_oracle_pfb_taps.h"
+
+static inline int32_t mulc45(int32_t t) { return (int32_t)(((int64_t)t * NVXO_PFB_C45) >> 15); }
+static inline int16_t clamp16(int32_t v) { return (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
+
+void nvxo_channelise(const int16_t *raw, size_t n_out, const int16_t *hist40, int16_t *out)
+{
+    for (size_t m = 0; m < n_out; m++) {
+        int32_t ur[8], ui[8];
+        for (int p = 0; p < 8; p++) {
+            int32_t re = 0, im = 0;
+            for (int j = p; j < NVXO_PFB_T; j += 8) {
+                const long n = (long)(8 * m) - 40 + j;              /* sample index of window slot j */
+                int32_t xi, xq;
+                if (n >= 0) { xi = raw[2 * n]; xq = raw[2 * n + 1]; }
+                else if (hist40) { xi = hist40[2 * (40 + n)]; xq = hist40[2 * (40 + n) + 1]; }
+                else { xi = 0; xq = 0; }
+                re += NVXO_PFB_H[47 - j] * xi;
+                im += NVXO_PFB_H[47 - j] * xq;
+            }
+            ur[p] = (re + 16) >> 5;
+            ui[p] = (im + 16) >> 5;
+        }
+        /* radix-2 decimation-in-time, forward transform e^{-j 2 pi k p / 8} */
+        int32_t ar[8], ai[8], br[8], bi[8], yr[8], yi[8];
+        ar[0] = ur[0] + ur[4]; ai[0] = ui[0] + ui[4];  ar[1] = ur[0] - ur[4]; ai[1] = ui[0] - ui[4];
+        ar[2] = ur[2] + ur[6]; ai[2] = ui[2] + ui[6];  ar[3] = ur[2] - ur[6]; ai[3] = ui[2] - ui[6];
+        ar[4] = ur[1] + ur[5]; ai[4] = ui[1] + ui[5];  ar[5] = ur[1] - ur[5]; ai[5] = ui[1] - ui[5];
+        ar[6] = ur[3] + ur[7]; ai[6] = ui[3] + ui[7];  ar[7] = ur[3] - ur[7]; ai[7] = ui[3] - ui[7];
+        /* (-j)(x + jy) = y - jx */
+        br[0] = ar[0] + ar[2]; bi[0] = ai[0] + ai[2];  br[2] = ar[0] - ar[2]; bi[2] = ai[0] - ai[2];
+        br[1] = ar[1] + ai[3]; bi[1] = ai[1] - ar[3];  br[3] = ar[1] - ai[3]; bi[3] = ai[1] + ar[3];
+        br[4] = ar[4] + ar[6]; bi[4] = ai[4] + ai[6];  br[6] = ar[4] - ar[6]; bi[6] = ai[4] - ai[6];
+        br[5] = ar[5] + ai[7]; bi[5] = ai[5] - ar[7];  br[7] = ar[5] - ai[7]; bi[7] = ai[5] + ar[7];
+        /* W1 = (1 - j)/sqrt2: W1 (x+jy) = ((x+y) + j(y-x))/sqrt2 ; W3 = (-1 - j)/sqrt2: ((y-x) + j(-x-y))/sqrt2 */
+        const int32_t w1r = mulc45(br[5] + bi[5]), w1i = mulc45(bi[5] - br[5]);
+        const int32_t w3r = mulc45(bi[7] - br[7]), w3i = mulc45(-br[7] - bi[7]);
+        yr[0] = br[0] + br[4]; yi[0] = bi[0] + bi[4];  yr[4] = br[0] - br[4]; yi[4] = bi[0] - bi[4];
+        yr[1] = br[1] + w1r;   yi[1] = bi[1] + w1i;    yr[5] = br[1] - w1r;   yi[5] = bi[1] - w1i;
+        yr[2] = br[2] + bi[6]; yi[2] = bi[2] - br[6];  yr[6] = br[2] - bi[6]; yi[6] = bi[2] + br[6];
+        yr[3] = br[3] + w3r;   yi[3] = bi[3] + w3i;    yr[7] = br[3] - w3r;   yi[7] = bi[3] - w3i;
+        for (int k = 0; k < 8; k++) {
+            out[2 * (k * n_out + m)]     = clamp16((yr[k] + 4096) >> 13);
+            out[2 * (k * n_out + m) + 1] = clamp16((yi[k] + 4096) >> 13);
+        }
+    }
+}
+
+/* ========================================================================== */
 /* decimating FIR, direct form, reference tap order                           */
 /* ========================================================================== */
 typedef struct {

@@ -39,6 +39,17 @@ extern "C" {
  * out[m] = (sum_{j<8} raw[8m+j] + 4) >> 3, per component, arithmetic shift.  */
 void nvxo_stage0(const int16_t *raw_iq, size_t n_out, int16_t *out_iq);
 
+/* ---- build-owned wideband front-end (no reference counterpart):
+ * 8-channel maximally decimated polyphase channeliser, integer arithmetic only.
+ * Sub-band k (0..7) is the 252 kHz-wide slice centred at k * 252 kHz (k >= 4: negative
+ * frequencies), delivered at 252 kS/s.  Exact definition, with x[n<0] = hist (40 samples,
+ * oldest first) or zero:
+ *   u[p] = ( sum_{j = p (mod 8), j < 48} h[47-j] * x[8m - 40 + j]  + 16 ) >> 5      (int32, per component)
+ *   Y[k] = 8-point DFT of u (radix-2 DIT below; 45-degree twiddles as 23170/2^15, floor shifts)
+ *   out[k][m] = clamp_int16( (Y[k] + 4096) >> 13 )
+ * out is [8][n_out] interleaved I,Q.                                                   */
+void nvxo_channelise(const int16_t *raw_iq, size_t n_out, const int16_t *hist40, int16_t *out);
+
 /* ---- whole-array stage functions, zero history (fir1cpp.C:80-136 etc.) ---- */
 size_t nvxo_fir1(const int16_t *iq, size_t n, double *y1);          /* returns n/4  */
 void   nvxo_mixer_table(double cr[NVXO_MIX_N], double ci[NVXO_MIX_N]);

@@ -30,7 +30,7 @@ L = C.CDLL(str(LIB))
 MSG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int)
 _vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
 for name, res, args in [
-    ("nvxo_stage0", None, [_vp, _sz, _vp]),
+    ("nvxo_stage0", None, [_vp, _sz, _vp]), ("nvxo_channelise", None, [_vp, _sz, _vp, _vp]),
     ("nvxo_fir1", _sz, [_vp, _sz, _vp]), ("nvxo_mix", None, [_vp, _sz, _i, _vp]),
     ("nvxo_fir2", _sz, [_vp, _sz, _vp]), ("nvxo_fir3", _sz, [_vp, _sz, _vp]),
     ("nvxo_mixer_table", None, [_vp, _vp]), ("nvxo_bitfilter_table", None, [_vp, _vp]),
@@ -57,6 +57,16 @@ def stage0(raw_iq: np.ndarray) -> np.ndarray:
     n_out = raw_iq.shape[0] // 8
     out = np.empty((n_out, 2), dtype=np.int16)
     L.nvxo_stage0(_p(raw_iq), n_out, _p(out))
+    return out
+
+
+def channelise(raw_iq: np.ndarray, hist40: np.ndarray | None = None) -> np.ndarray:
+    """Wideband front-end: [n*8, 2] int16 at 2.016 MS/s -> [8, n, 2] int16 at 252 kS/s."""
+    raw_iq = np.ascontiguousarray(raw_iq, dtype=np.int16).reshape(-1, 2)
+    n_out = raw_iq.shape[0] // 8
+    out = np.empty((8, n_out, 2), dtype=np.int16)
+    h = None if hist40 is None else np.ascontiguousarray(hist40, dtype=np.int16).reshape(40, 2)
+    L.nvxo_channelise(_p(raw_iq), n_out, _p(h) if h is not None else None, _p(out))
     return out
 
 

@@ -1,0 +1,135 @@
+"""Wideband front-end (build-owned): the 8-channel polyphase
+channeliser.  CPU: the scalar restatement against an ideal float filter bank.
+GPU: the HIP kernel bit-exact against the restatement, and a wideband stream with
+16 NAVTEX carriers decoded end to end."""
+import numpy as np
+import pytest
+
+FS = 2016000
+
+
+def tone(freq, n, amp=8000.0):
+    t = np.arange(n)
+    x = amp * np.exp(2j * np.pi * freq * t / FS)
+    return np.stack([np.round(x.real), np.round(x.imag)], 1).astype(np.int16)
+
+
+def ideal_filterbank(raw, taps_q18):
+    """float64 reference: mix each sub-band to DC, FIR with the same taps, decimate by 8
+    (newest sample of output m is 8m+7)."""
+    x = raw[:, 0].astype(np.float64) + 1j * raw[:, 1].astype(np.float64)
+    h = np.asarray(taps_q18, dtype=np.float64) / (1 << 18)
+    n = np.arange(x.size)
+    out = []
+    for k in range(8):
+        y = np.convolve(x * np.exp(-2j * np.pi * k * n / 8), h)[: x.size]
+        out.append(y[7::8])
+    return np.array(out)
+
+
+def taps():
+    import re
+    from pathlib import Path
+    src = (Path(__file__).resolve().parent.parent / "navtex_amd" / "csrc" / "nvx_pfb_taps.h").read_text()
+    body = src[src.index("NVX_PFB_H[48]"):]
+    return [int(v) for v in re.findall(r"-?\d+", body[body.index("{"): body.index("}")])]
+
+
+def test_taps_are_shared_and_sane():
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    a = (root / "navtex_amd" / "csrc" / "nvx_pfb_taps.h").read_text().split("{")[1]
+    b = (root / "oracle" / "nvx_oracle_pfb_taps.h").read_text().split("{")[1]
+    assert a == b
+    h = taps()
+    assert len(h) == 48 and sum(h) == 1 << 18 and h == h[::-1] and max(map(abs, h)) < 32768
+
+
+def test_restatement_is_a_filter_bank(oracle):
+    rng = np.random.default_rng(4)
+    n = 8 * 3000
+    raw = (tone(14000, n, 3000).astype(np.int32) + tone(252000 - 14000, n, 2500) + tone(-3 * 252000 + 5000, n, 2000)
+           + rng.integers(-1500, 1501, size=(n, 2))).astype(np.int16)
+    got = oracle.channelise(raw).astype(np.float64)
+    got = got[:, :, 0] + 1j * got[:, :, 1]
+    want = ideal_filterbank(raw, taps())
+    err = np.abs(got - want)[:, 8:]                      # skip the start-up of the FIR
+    assert err.max() < 3.0                                # integer rounding only (a few LSB of 2^15)
+    power = (np.abs(got[:, 100:]) ** 2).mean(axis=1)
+    assert np.argsort(power)[-3:].tolist().sort() == [0, 1, 5].sort()
+
+
+def test_restatement_history_chaining(oracle):
+    rng = np.random.default_rng(5)
+    raw = rng.integers(-32768, 32768, size=(8 * 640, 2), dtype=np.int16)
+    whole = oracle.channelise(raw)
+    a = oracle.channelise(raw[: 8 * 256])
+    b = oracle.channelise(raw[8 * 256:], hist40=raw[8 * 256 - 40: 8 * 256])
+    assert np.array_equal(whole, np.concatenate([a, b], axis=1))
+
+
+@pytest.mark.gpu
+def test_kernel_bit_exact_full_scale_random(nv, oracle):
+    rng = np.random.default_rng(6)
+    n_wide, n_out = 3, 64 * 40
+    raw = rng.integers(-32768, 32768, size=(n_wide, 8 * n_out, 2), dtype=np.int16)
+    raw[0, :4000] = 32767; raw[1, :4000] = -32768           # saturating stretches -> clamp path
+    pitch_raw, pitch_sub = 8 * n_out + 8, n_out + 4
+    d_raw = nv.DeviceBuffer(n_wide * pitch_raw * 4); d_sub = nv.DeviceBuffer(n_wide * 8 * pitch_sub * 4)
+    h0, h1 = nv.DeviceBuffer(n_wide * 40 * 4), nv.DeviceBuffer(n_wide * 40 * 4)
+    for w in range(n_wide):
+        d_raw.upload(raw[w], offset=w * pitch_raw * 4)
+    first = 64 * 24
+    # two calls with carried history == one call == the restatement
+    nv.channelise(d_raw, pitch_raw, 0, n_wide, first, d_sub, pitch_sub, 0, hist_in=None, hist_out=h0)
+    nv.channelise(d_raw, pitch_raw, 8 * first, n_wide, n_out - first, d_sub, pitch_sub, first, hist_in=h0, hist_out=h1)
+    got = d_sub.download(n_wide * 8 * pitch_sub * 4, dtype=np.int16).reshape(n_wide * 8, pitch_sub, 2)[:, :n_out]
+    for w in range(n_wide):
+        want = oracle.channelise(raw[w])
+        assert np.array_equal(got[8 * w: 8 * w + 8], want), f"wide stream {w}"
+    assert np.array_equal(h1.download(n_wide * 40 * 4, dtype=np.int16).reshape(n_wide, 40, 2), raw[:, -40:])
+    for b in (d_raw, d_sub, h0, h1):
+        b.free()
+
+
+@pytest.mark.gpu
+def test_sixteen_carriers_from_one_wideband_stream(nv, oracle):
+    """One 2.016 MS/s stream with a NAVTEX carrier at k*252 kHz +-14 kHz for every k: the
+    channeliser + the 252 kS/s pipeline decode all 16 messages, bits identical to the
+    restatement chain (channeliser restatement -> oracle pipeline)."""
+    n_frames = 36                                       # 11.5 s: phasing (2.8 s) + ~45 characters twice (6.3 s) + priming
+    n = n_frames * nv.FRAME_RAW
+    total = np.zeros((n, 2), dtype=np.int32)
+    texts = {}
+    for k in range(8):
+        centre = k * 252000 if k < 4 else (k - 8) * 252000
+        carriers = []
+        for c, off in ((0, 14000), (1, -14000)):
+            txt = f"ZCZC W{chr(65 + k)}{k}{c}\nBAND {k} CHAIN {c}\nNNNN\n"
+            texts[(k, c)] = txt
+            carriers.append(dict(freq_hz=centre + off, bits=nv.sitor_encode(txt, 20), bit_offset=(977 * (2 * k + c + 1)) % 20160,
+                                 phase0=(123456789 * (2 * k + c + 1)) % 2**32, amplitude=1700))
+        total += nv.synth_host(nv.make_stream(carriers, seed=k, noise_amp=0), nv.RATE_RAW, n)
+    rng = np.random.default_rng(0)
+    total += rng.integers(-600, 601, size=total.shape)
+    raw = np.clip(total, -32768, 32767).astype(np.int16)
+
+    n_out = n // 8
+    d_raw = nv.DeviceBuffer(n * 4); d_sub = nv.DeviceBuffer(8 * n_out * 4)
+    d_raw.upload(raw)
+    nv.channelise(d_raw, n, 0, 1, n_out, d_sub, n_out)
+    sub = oracle.channelise(raw)
+    assert np.array_equal(d_sub.download(8 * n_out * 4, dtype=np.int16).reshape(8, n_out, 2), sub)
+
+    labels = [[1000 * (k + 1) + 518, 1000 * (k + 1) + 490] for k in range(8)]
+    with nv.Pipeline(n_streams=8, raw_rate=False, chain_mask=3, labels=labels, max_frames=n_frames) as p:
+        p.process_resident(d_sub, n_out, 0, n_frames)
+        p.fetch()
+        got = {(s, f % 1000): (b, m) for (s, f, b, m) in p.messages}
+        for k in range(8):
+            ref = oracle.Pipe(chain_mask=3, charlayer=False)
+            ref.push(sub[k])
+            for c, f in ((0, 518), (1, 490)):
+                assert p.bits(k, c) == ref.bits(c), f"band {k} chain {c}"
+                assert got[(k, f)] == (f"W{chr(65 + k)}{k}{c}", texts[(k, c)]), f"band {k} chain {c}"
+    d_raw.free(); d_sub.free()
