@@ -45,10 +45,118 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-charlayer", action="store_true")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra complex samples between streams (multiple of 4)")
+    ap.add_argument("--wideband", type=int, default=0, metavar="W",
+                    help="wideband mode (SURVEY 8f rank 2, not the headline): W streams at 2.016 MS/s per GPU, each carrying "
+                         "16 NAVTEX carriers; channeliser -> 8W sub-bands at 252 kS/s -> both chains")
     ap.add_argument("--variant-a", action="store_true",
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
     return ap.parse_args()
+
+
+def wideband_streams(nv, signals, rank, W, n_phasing=40):
+    """W wideband streams: a carrier at k*252 kHz +-14 kHz for k = 0..7, each with its own text."""
+    out = []
+    for w in range(W):
+        gid = rank * W + w
+        carriers = []
+        for k in range(8):
+            centre = k * 252000 if k < 4 else (k - 8) * 252000
+            for c, off in ((0, 14000), (1, -14000)):
+                cid = gid * 16 + 2 * k + c
+                h = signals.mix32(signals.GLOBAL_SEED ^ signals.mix32(cid + 0x10000))
+                carriers.append(dict(freq_hz=centre + off, bits=nv.sitor_encode(signals.stream_text(cid), n_phasing),
+                                     bit_offset=(signals.mix32(h ^ 0xA5A5A5A5) % 20160) | 1, phase0=signals.mix32(h ^ 0x3C3C3C3C),
+                                     amplitude=1700))
+        out.append(nv.make_stream(carriers, seed=signals.mix32(gid + 77), noise_amp=600))
+    return out
+
+
+def run_wideband(args, nv, signals, torch, dist, rank, world, device, backend):
+    """Channeliser + 252 kS/s pipeline on W wideband streams per GPU."""
+    W, F = args.wideband, args.frames
+    n_raw, n_sub = F * nv.FRAME_RAW, F * nv.FRAME_IN
+    t0 = time.time()
+    raw = nv.DeviceBuffer(W * n_raw * 4, device=device)
+    sub = nv.DeviceBuffer(8 * W * n_sub * 4, device=device)
+    nv.synth_device(wideband_streams(nv, signals, rank, W), nv.RATE_RAW, n_raw, raw, n_raw)
+    t_gen = time.time() - t0
+    pipe = nv.Pipeline(n_streams=8 * W, raw_rate=False, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device)
+    st = pipe.hip_stream
+
+    def step():
+        nv.channelise(raw, n_raw, 0, W, n_sub, sub, n_sub, hip_stream=st)
+        pipe.process_resident(sub, n_sub, 0, F, hip_stream=st)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize(device)
+
+    cpu, parity = None, None
+    if rank == 0:
+        import oracle_binding as ob
+        ncpu = int(os.environ.get("NVX_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
+        nw = min(W, 2 if world > 1 else max(2, ncpu // 4))
+        sample = raw.download(nw * n_raw * 4, dtype=np.int16).reshape(nw, n_raw, 2)
+        step(); pipe.fetch()
+        gpu_bits = [pipe.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
+        sN, cpu_bits = ob.bench_wide(sample, nw, n_sub, ncpu, want_bits=True)
+        if not args.no_cpu and world == 1:
+            rep = max(1, int(5.0 / max(sN, 1e-3)))
+            sN = ob.bench_wide(sample, nw, n_sub, ncpu, repeat=rep)[0]
+            s1 = ob.bench_wide(sample[:1], 1, n_sub, 1, repeat=max(1, rep // 8))[0]
+            cpu = {"value": round(nw * n_raw * rep / sN / 1e6, 2), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
+                   "value_1thread": round(n_raw * max(1, rep // 8) / s1 / 1e6, 2),
+                   "sample": f"all {F} frames of the first {nw} wideband streams ({nw * n_raw / 1e6:.0f} M raw samples), processed {rep}x; "
+                             f"oracle channeliser + 8 x 2-chain 252 kS/s pipes, OpenMP over streams", "seconds": round(sN, 2)}
+        parity = gpu_bits == cpu_bits and all(len(b) > 0 for b in cpu_bits)
+        if not parity:
+            print("PARITY FAILURE (wideband): GPU bits differ from the CPU oracle", file=sys.stderr)
+    pipe.reset()
+    for _ in range(args.warmup):
+        step()
+    pipe.fetch()
+    pipe.enable_timing(True); pipe.kernel_time_stats(0, reset=True)
+    nv.lib.nvx_channelise_timing(1); nv.channelise_time_stats(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    pipe.fetch()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    casc_ms, n_l = pipe.kernel_time_stats(0)
+    dem_ms, _ = pipe.kernel_time_stats(1)
+    ch_ms, n_c = nv.channelise_time_stats()
+    if rank == 0:
+        casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
+        sub_bytes = 8 * W * n_sub * 4
+        line = {
+            "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(world * W * n_raw * args.steps / elapsed / 1e6, 1),
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"WIDEBAND (SURVEY 8f-2, not the headline): {W} streams x 2.016 MS/s per GPU, 16 NAVTEX carriers each "
+                                   f"(8 sub-bands x 2 chains), {F} frames ({F * 0.32:.2f} s) resident in HBM",
+                       "wide_streams_per_gpu": W, "carriers_per_gpu": 16 * W, "frames": F,
+                       "parallelism": f"wideband streams sharded {world} ways, no collective"},
+            "carriers_decoded": 16 * W * world,
+            "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
+            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<252k,2>", "achieved": round(sub_bytes / (casc_avg * 1e-3) / 1e9, 1) if casc_avg else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sub_bytes / (casc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if casc_avg else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": sub_bytes, "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),
+                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
+                         "note": "fp64-issue-bound by design at 252 kS/s (DESIGN.md 3.1, Variant A)"},
+            "channeliser": {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
+                            "read_plus_write_gbs": round((W * n_raw * 4 + sub_bytes) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
+            "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(t_gen, 1),
+        }
+        print(json.dumps(line), flush=True)
+    pipe.close(); raw.free(); sub.free()
 
 
 def main():
@@ -81,6 +189,11 @@ def main():
 
     if nv.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
+    if args.wideband:
+        run_wideband(args, nv, signals, torch, dist, rank, world, device, backend)
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     S, F = args.streams, args.frames
     raw = not args.variant_a
     RATE, FRAME = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)

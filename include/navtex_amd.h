@@ -261,11 +261,12 @@ typedef struct nvx_carrier {
     const char *bits;        /* 'B'/'Y' (host pointer)                                    */
 } nvx_carrier;
 
+#define NVX_SYNTH_MAX_CARRIERS 16     /* a wideband stream: 8 sub-bands x 2 chains             */
 typedef struct nvx_synth_stream {
     uint32_t seed;
     int32_t  noise_amp;      /* uniform integer noise in [-noise_amp, +noise_amp]         */
-    int32_t  n_carriers;     /* 0..2                                                      */
-    nvx_carrier carrier[2];
+    int32_t  n_carriers;     /* 0..NVX_SYNTH_MAX_CARRIERS                                 */
+    nvx_carrier carrier[NVX_SYNTH_MAX_CARRIERS];
 } nvx_synth_stream;
 
 /* host generator: n complex samples starting at sample index n0, sample_rate
@@ -291,6 +292,12 @@ NVX_API int nvx_synth_device(int device, const nvx_synth_stream *streams, int n_
  *    (NULL in = silence before the first sample; NULL out = not saved; in != out).
  * ========================================================================== */
 #define NVX_WB_SUBBANDS 8
+/* the handle's own HIP stream (a hipStream_t), so a channeliser launch can be ordered in front of
+ * nvx_process_resident(..., hip_stream = that stream) without a device-wide synchronise      */
+NVX_API void *nvx_handle_stream(nvx_handle *h);
+/* optional HIP-event timing of the channeliser launches (off by default)                  */
+NVX_API void nvx_channelise_timing(int enable);
+NVX_API int  nvx_channelise_time_stats(double *sum_ms, uint64_t *launches, int reset);
 NVX_API int nvx_channelise_resident(int device, const void *d_raw, size_t pitch_raw, size_t first_sample,
                                     int n_wide, size_t n_out, const void *d_hist_in, void *d_hist_out,
                                     void *d_sub, size_t pitch_sub, size_t sub_first, void *hip_stream);

@@ -17,7 +17,7 @@ from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRA
                       NvxError, lib)
 
 __all__ = ["Pipeline", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
-           "DeviceBuffer", "channelise", "wav_write", "wav_read", "NvxError", "lib",
+           "DeviceBuffer", "channelise", "channelise_time_stats", "wav_write", "wav_read", "NvxError", "lib",
            "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
 
 
@@ -121,12 +121,22 @@ def synth_device(streams: Sequence[N.SynthStream], rate: int, n: int, buf: Devic
 
 
 def channelise(raw: "DeviceBuffer", pitch_raw: int, first_sample: int, n_wide: int, n_out: int, sub: "DeviceBuffer", pitch_sub: int,
-               sub_first: int = 0, hist_in: Optional["DeviceBuffer"] = None, hist_out: Optional["DeviceBuffer"] = None) -> None:
-    """Wideband front-end (nvx_channelise_resident): n_wide streams at 2.016 MS/s -> 8*n_wide sub-bands at 252 kS/s."""
+               sub_first: int = 0, hist_in: Optional["DeviceBuffer"] = None, hist_out: Optional["DeviceBuffer"] = None,
+               hip_stream: Optional[int] = None) -> None:
+    """Wideband front-end (nvx_channelise_resident): n_wide streams at 2.016 MS/s -> 8*n_wide sub-bands at 252 kS/s.
+    Without hip_stream it runs on the null stream and the device is synchronised afterwards; with the
+    stream of a Pipeline (Pipeline.hip_stream) it is simply ordered in front of that pipeline's launches."""
     N.check(lib.nvx_channelise_resident(raw.device, raw.ptr, pitch_raw, first_sample, n_wide, n_out,
                                         hist_in.ptr if hist_in else None, hist_out.ptr if hist_out else None,
-                                        sub.ptr, pitch_sub, sub_first, None), "nvx_channelise_resident")
-    N.check(lib.nvx_device_sync(raw.device), "nvx_device_sync")
+                                        sub.ptr, pitch_sub, sub_first, hip_stream), "nvx_channelise_resident")
+    if hip_stream is None:
+        N.check(lib.nvx_device_sync(raw.device), "nvx_device_sync")
+
+
+def channelise_time_stats(reset: bool = False):
+    s, n = C.c_double(), C.c_uint64()
+    N.check(lib.nvx_channelise_time_stats(C.byref(s), C.byref(n), int(reset)), "nvx_channelise_time_stats")
+    return s.value, n.value
 
 
 # ------------------------------------------------------------------ pipeline
@@ -173,9 +183,13 @@ class Pipeline:
         return N.check(lib.nvx_decode_wav(self._h, stream, path.encode()), "nvx_decode_wav")
 
     # resident input -------------------------------------------------------
-    def process_resident(self, buf: DeviceBuffer, pitch: int, first_frame: int, n_frames: int, hip_stream: int = 0) -> None:
+    def process_resident(self, buf: DeviceBuffer, pitch: int, first_frame: int, n_frames: int, hip_stream: Optional[int] = None) -> None:
         N.check(lib.nvx_process_resident(self._h, buf.ptr, pitch, first_frame, n_frames, hip_stream or None),
                 "nvx_process_resident")
+
+    @property
+    def hip_stream(self) -> int:
+        return lib.nvx_handle_stream(self._h)
 
     def fetch(self) -> None:
         N.check(lib.nvx_fetch_bits(self._h), "nvx_fetch_bits")

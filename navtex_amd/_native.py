@@ -40,7 +40,7 @@ class Carrier(C.Structure):
 
 
 class SynthStream(C.Structure):
-    _fields_ = [("seed", C.c_uint32), ("noise_amp", C.c_int32), ("n_carriers", C.c_int32), ("carrier", Carrier * 2)]
+    _fields_ = [("seed", C.c_uint32), ("noise_amp", C.c_int32), ("n_carriers", C.c_int32), ("carrier", Carrier * 16)]
 
 
 def _load() -> C.CDLL:
@@ -84,6 +84,8 @@ def _load() -> C.CDLL:
         "nvx_synth_device": (i, [i, C.POINTER(SynthStream), i, u32, sz, vp, sz]),
         "nvx_atan2_host": (C.c_double, [C.c_double, C.c_double]),
         "nvx_channelise_resident": (i, [i, vp, sz, sz, i, sz, vp, vp, vp, sz, sz, vp]),
+        "nvx_handle_stream": (vp, [vp]), "nvx_channelise_timing": (None, [i]),
+        "nvx_channelise_time_stats": (i, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

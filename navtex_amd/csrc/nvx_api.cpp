@@ -619,7 +619,7 @@ extern "C" int nvx_synth_device(int device, const nvx_synth_stream *streams, int
     std::vector<nvx_period> pool;
     for (int s = 0; s < n_streams; s++) {
         const nvx_synth_stream &st = streams[s];
-        if (st.n_carriers < 0 || st.n_carriers > 2) { nvx_set_error("nvx_synth_device: stream %d: bad carrier count", s); return NVX_ERR_ARG; }
+        if (st.n_carriers < 0 || st.n_carriers > NVX_SYNTH_MAX_CARRIERS) { nvx_set_error("nvx_synth_device: stream %d: bad carrier count", s); return NVX_ERR_ARG; }
         nvx_synth_desc &d = desc[s];
         memset(&d, 0, sizeof d);
         d.seed = st.seed; d.noise_amp = st.noise_amp; d.n_carriers = st.n_carriers;
@@ -650,6 +650,34 @@ extern "C" int nvx_synth_device(int device, const nvx_synth_stream *streams, int
 }
 
 // ------------------------------------------------------------ wideband front-end
+extern "C" void *nvx_handle_stream(nvx_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+static struct ChanTiming {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool, pending;
+    double sum_ms = 0.0; uint64_t n = 0;
+} g_ct;
+
+extern "C" void nvx_channelise_timing(int enable) { std::lock_guard<std::mutex> lk(g_ct.mu); g_ct.on = enable != 0; }
+
+extern "C" int nvx_channelise_time_stats(double *sum_ms, uint64_t *launches, int reset)
+{
+    std::lock_guard<std::mutex> lk(g_ct.mu);
+    for (auto &p : g_ct.pending) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        g_ct.sum_ms += ms; g_ct.n++;
+        g_ct.pool.push_back(p);
+    }
+    g_ct.pending.clear();
+    if (sum_ms) *sum_ms = g_ct.sum_ms;
+    if (launches) *launches = g_ct.n;
+    if (reset) { g_ct.sum_ms = 0.0; g_ct.n = 0; }
+    return NVX_OK;
+}
+
 extern "C" int nvx_channelise_resident(int device, const void *d_raw, size_t pitch_raw, size_t first_sample, int n_wide,
                                        size_t n_out, const void *d_hist_in, void *d_hist_out, void *d_sub, size_t pitch_sub,
                                        size_t sub_first, void *hip_stream)
@@ -669,7 +697,23 @@ extern "C" int nvx_channelise_resident(int device, const void *d_raw, size_t pit
     size_t cpb = (n_chunks * (size_t)n_wide + 16383) / 16384;
     if (cpb < 8) cpb = 8;
     a.chunks_per_block = (int)std::min<size_t>(cpb, n_chunks);
+    std::pair<hipEvent_t, hipEvent_t> ev{ nullptr, nullptr };
+    bool timed = false;
+    {
+        std::lock_guard<std::mutex> lk(g_ct.mu);
+        if (g_ct.on) {
+            if (g_ct.pool.empty()) { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+            else { ev = g_ct.pool.back(); g_ct.pool.pop_back(); }
+            timed = true;
+        }
+    }
+    if (timed) HIP_TRY(hipEventRecord(ev.first, (hipStream_t)hip_stream));
     HIP_TRY(nvx_launch_channelise(&a, (hipStream_t)hip_stream));
+    if (timed) {
+        HIP_TRY(hipEventRecord(ev.second, (hipStream_t)hip_stream));
+        std::lock_guard<std::mutex> lk(g_ct.mu);
+        g_ct.pending.push_back(ev);
+    }
     return NVX_OK;
 }
 

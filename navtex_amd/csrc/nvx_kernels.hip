@@ -736,31 +736,29 @@ __global__ __launch_bounds__(256) void nvx_synth_kernel(nvx_synth_args a)
     const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // 4 samples per thread
     const size_t n0 = quad * 4;
     if (n0 >= a.n) return;
-    const nvx_synth_desc d = a.desc[stream];
-    uint32_t ph[2] = { 0, 0 }, inc[2] = { 0, 0 }, r[2] = { 0, 0 };
-    size_t b[2] = { 0, 0 };
-    for (int c = 0; c < d.n_carriers; c++) {
-        const uint64_t g = (uint64_t)n0 + d.bit_offset[c];
-        b[c] = (size_t)(g / a.spb);
-        r[c] = (uint32_t)(g - (uint64_t)b[c] * a.spb);
-        const nvx_period p = a.pool[d.pool_off[c] + b[c]];
-        inc[c] = p.inc; ph[c] = p.phase + r[c] * p.inc;
+    const nvx_synth_desc *d = a.desc + stream;
+    int32_t I[4] = { 0, 0, 0, 0 }, Q[4] = { 0, 0, 0, 0 };
+    const int nc = d->n_carriers;
+    for (int c = 0; c < nc; c++) {                    // carrier-major: the 4-sample arrays keep static indices
+        const uint64_t g = (uint64_t)n0 + d->bit_offset[c];
+        size_t b = (size_t)(g / a.spb);
+        uint32_t r = (uint32_t)(g - (uint64_t)b * a.spb);
+        const nvx_period *pool = a.pool + d->pool_off[c];
+        nvx_period p = pool[b];
+        uint32_t ph = p.phase + r * p.inc;
+        const int32_t amp = d->amp[c];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            nvx_synth_tone(ph, amp, &I[k], &Q[k]);
+            ph += p.inc;
+            if (++r == a.spb) { r = 0; b++; p = pool[b]; ph = p.phase; }     // next bit period
+        }
     }
     uint32_t w[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int32_t I = 0, Q = 0;
-        for (int c = 0; c < d.n_carriers; c++) {
-            nvx_synth_tone(ph[c], d.amp[c], &I, &Q);
-            ph[c] += inc[c];
-            if (++r[c] == a.spb) {                 // next bit period
-                r[c] = 0; b[c]++;
-                const nvx_period p = a.pool[d.pool_off[c] + b[c]];
-                inc[c] = p.inc; ph[c] = p.phase;
-            }
-        }
-        if (d.noise_amp > 0) nvx_synth_noise(d.seed, (uint64_t)(n0 + k), d.noise_amp, &I, &Q);
-        w[k] = nvx_synth_pack(I, Q);
+        if (d->noise_amp > 0) nvx_synth_noise(d->seed, (uint64_t)(n0 + k), d->noise_amp, &I[k], &Q[k]);
+        w[k] = nvx_synth_pack(I[k], Q[k]);
     }
     uint32_t *out = a.out + (size_t)stream * a.pitch + n0;
     if (n0 + 4 <= a.n) {

@@ -31,13 +31,14 @@
 typedef struct { uint32_t phase; uint32_t inc; } nvx_period;
 
 /* flattened per-stream description the device kernel reads */
+#define NVX_SYNTH_CARRIERS 16
 typedef struct {
     uint32_t seed;
     int32_t  noise_amp;
     int32_t  n_carriers;
-    int32_t  amp[2];
-    uint32_t bit_offset[2];
-    uint32_t pool_off[2];      /* first nvx_period of this carrier in the pool */
+    int32_t  amp[NVX_SYNTH_CARRIERS];
+    uint32_t bit_offset[NVX_SYNTH_CARRIERS];
+    uint32_t pool_off[NVX_SYNTH_CARRIERS];   /* first nvx_period of this carrier in the pool */
 } nvx_synth_desc;
 
 NVX_SHD uint32_t nvx_hash32(uint32_t x)

@@ -32,19 +32,19 @@ void nvx_synth_periods(const nvx_carrier *c, uint32_t sample_rate, uint64_t firs
 int nvx_synth_host(const nvx_synth_stream *s, uint32_t sample_rate, uint64_t n0, size_t n, int16_t *out)
 {
     if (!s || !out || (sample_rate != NVX_RATE_RAW && sample_rate != NVX_RATE_IN) ||
-        s->n_carriers < 0 || s->n_carriers > 2) {
+        s->n_carriers < 0 || s->n_carriers > NVX_SYNTH_MAX_CARRIERS) {
         nvx_set_error("nvx_synth_host: bad argument");
         return NVX_ERR_ARG;
     }
     const uint32_t spb = sample_rate / 100;
-    nvx_period *per[2] = { NULL, NULL };
-    uint64_t first[2] = { 0, 0 };
+    nvx_period *per[NVX_SYNTH_MAX_CARRIERS] = { NULL };
+    uint64_t first[NVX_SYNTH_MAX_CARRIERS] = { 0 };
     for (int c = 0; c < s->n_carriers; c++) {
         if (s->carrier[c].bit_offset >= spb) { nvx_set_error("nvx_synth_host: bit_offset >= samples per bit"); return NVX_ERR_ARG; }
         first[c] = (n0 + s->carrier[c].bit_offset) / spb;
         uint64_t last = (n0 + n + s->carrier[c].bit_offset) / spb;
         per[c] = (nvx_period *)malloc((size_t)(last - first[c] + 1) * sizeof(nvx_period));
-        if (!per[c]) { free(per[0]); nvx_set_error("nvx_synth_host: out of memory"); return NVX_ERR_NOMEM; }
+        if (!per[c]) { for (int k = 0; k < c; k++) free(per[k]); nvx_set_error("nvx_synth_host: out of memory"); return NVX_ERR_NOMEM; }
         nvx_synth_periods(&s->carrier[c], sample_rate, first[c], (size_t)(last - first[c] + 1), per[c]);
     }
     uint32_t *o = (uint32_t *)out;
@@ -62,6 +62,6 @@ int nvx_synth_host(const nvx_synth_stream *s, uint32_t sample_rate, uint64_t n0,
         uint32_t w = nvx_synth_pack(I, Q);
         memcpy(&o[k], &w, 4);
     }
-    free(per[0]); free(per[1]);
+    for (int c = 0; c < s->n_carriers; c++) free(per[c]);
     return NVX_OK;
 }

@@ -736,3 +736,35 @@ double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int cha
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+double nvxo_bench_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthreads, int repeat, char *bits_out, size_t cap)
+{
+    struct timespec t0, t1;
+    if (nthreads < 1) nthreads = 1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (long job = 0; job < (long)nwide * repeat; job++) {
+        const long w = job % (long)nwide;
+        int16_t *sub = malloc(8 * n_out * 2 * sizeof(int16_t));
+        nvxo_channelise(raw + (size_t)w * n_out * 16, n_out, NULL, sub);
+        for (int k = 0; k < 8; k++) {
+            nvxo_pipe *p = nvxo_pipe_new(3, 518, 490, NULL, NULL);
+            nvxo_pipe_set_charlayer(p, 0);
+            nvxo_pipe_push(p, sub + (size_t)k * n_out * 2, n_out);
+            if (bits_out && job < (long)nwide) {
+                for (int c = 0; c < 2; c++) {
+                    size_t nb; const char *b = nvxo_pipe_bits(p, c, &nb);
+                    if (nb >= cap) nb = cap - 1;
+                    char *dst = bits_out + ((size_t)(w * 8 + k) * 2 + c) * cap;
+                    memcpy(dst, b, nb); dst[nb] = 0;
+                }
+            }
+            nvxo_pipe_free(p);
+        }
+        free(sub);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -112,6 +112,10 @@ void       nvxo_pipe_set_charlayer(nvxo_pipe *p, int enabled);
  * with NUL-terminated strings of chain 0 when non-NULL.                       */
 double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int chain_mask,
                   int nthreads, int repeat, char *bits_out, size_t cap);
+/* wideband CPU baseline: raw is [nwide][n_out*8] at 2.016 MS/s; each stream is channelised
+ * and its 8 sub-bands run through 252 kS/s pipes with both chains.  bits_out (optional):
+ * [nwide*16][cap] NUL-terminated, index (w*8 + k)*2 + chain.                             */
+double nvxo_bench_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthreads, int repeat, char *bits_out, size_t cap);
 int    nvxo_max_threads(void);
 
 #ifdef __cplusplus

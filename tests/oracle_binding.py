@@ -43,6 +43,7 @@ for name, res, args in [
     ("nvxo_pipe_tap_y3", None, [_vp, _i, _vp, _sz, C.POINTER(_sz)]),
     ("nvxo_pipe_set_charlayer", None, [_vp, _i]),
     ("nvxo_bench", C.c_double, [_vp, _sz, _sz, _i, _i, _i, _i, _vp, _sz]), ("nvxo_max_threads", _i, []),
+    ("nvxo_bench_wide", C.c_double, [_vp, _sz, _sz, _i, _i, _vp, _sz]),
 ]:
     fn = getattr(L, name)
     fn.restype, fn.argtypes = res, args
@@ -189,6 +190,16 @@ def bench(iq: np.ndarray, nstreams: int, n: int, raw: bool, chain_mask: int, nth
     bits = None
     if want_bits:
         bits = [buf.raw[s * cap:(s + 1) * cap].split(b"\0")[0].decode("ascii") for s in range(nstreams)]
+    return secs, bits
+
+
+def bench_wide(raw: np.ndarray, nwide: int, n_out: int, nthreads: int, repeat: int = 1, want_bits: bool = False):
+    """Timed wideband CPU baseline; raw is [nwide, n_out*8, 2] int16.  Returns (seconds, bits[nwide*16])."""
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    cap = n_out // 2520 + 64
+    buf = C.create_string_buffer(nwide * 16 * cap) if want_bits else None
+    secs = L.nvxo_bench_wide(_p(raw), nwide, n_out, nthreads, repeat, buf, cap)
+    bits = [buf.raw[i * cap:(i + 1) * cap].split(b"\0")[0].decode("ascii") for i in range(nwide * 16)] if want_bits else None
     return secs, bits
 
 
