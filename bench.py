@@ -184,6 +184,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if not (ROOT / "navtex_amd" / "libnavtex_amd.so").exists():       # fresh checkout: build first (hipcc, gfx950)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("nvx_build", ROOT / "navtex_amd" / "build.py")
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        if rank == 0:
+            mod.build_lib()
+        if dist is not None:
+            dist.barrier()
     import navtex_amd as nv
     import signals
 
