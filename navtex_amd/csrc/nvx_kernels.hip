@@ -64,20 +64,28 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vect
 // MIX:   9 + 9 doubles
 #define XS 74
 #define X_ENTRIES (4 * XS)
-#define U_ENTRIES 336
-#define U_RUN 224
 #ifndef NVX_Y2_RUN
-#define NVX_Y2_RUN 160                    /* FIR2 outputs per FIR3 run: 160 (16 outputs) or 80 (8 outputs) */
+#define NVX_Y2_RUN 160                    /* single-chain kernel: FIR2 outputs per FIR3 run, 160 (16 outputs) or 80 */
 #endif
-#define Y2_RUN NVX_Y2_RUN
-#define Y3_PER_RUN (Y2_RUN / 10)
-#define Y2_ENTRIES (((70 + Y2_RUN + 31) + 7) / 8 * 8)
+
+// Batching geometry.  One chain: FIR2 runs on 224 pending mixer outputs (32 outputs x {I,Q} = 64
+// lanes), FIR3 on NVX_Y2_RUN pending FIR2 outputs.  Two chains: both chains share a run
+// (lane = chain x output x component), so half the batch fills the wave and the pending
+// buffers -- and with them the LDS footprint -- halve: 17.4 KB instead of 24 KB, 9 instead of 6
+// waves per CU.  Either way a frame (20160 / 2880 outputs) is a whole number of runs.
+template <int NCH> struct Geo;
+template <> struct Geo<1> { static constexpr int U_RUN = 224, Y2_PER_RUN = 32, Y2_RUN = NVX_Y2_RUN, Y3_PER_RUN = NVX_Y2_RUN / 10; };
+template <> struct Geo<2> { static constexpr int U_RUN = 112, Y2_PER_RUN = 16, Y2_RUN = 80, Y3_PER_RUN = 8; };
+template <int NCH> struct GeoSizes {
+    static constexpr int U_ENTRIES = ((46 + Geo<NCH>::U_RUN + 63) + 7) / 8 * 8;
+    static constexpr int Y2_ENTRIES = ((70 + Geo<NCH>::Y2_RUN + Geo<NCH>::Y2_PER_RUN - 1) + 7) / 8 * 8;
+};
 
 template <int NCH>
 struct CascadeLds {
     double2 X[X_ENTRIES];
-    double2 U[NCH][U_ENTRIES];
-    double2 Y2[NCH][Y2_ENTRIES];
+    double2 U[NCH][GeoSizes<NCH>::U_ENTRIES];
+    double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES];
     double  mix[2 * NVX_MIX_N];
 };
 
@@ -288,54 +296,60 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
             }
             NVX_WAVE_LDS_FENCE();
 
-            // ---- 6. FIR2 when 224 mixer outputs are pending ---------------------
+            // ---- 6. FIR2 when a batch of mixer outputs is pending -----------------
+            constexpr int U_RUN = Geo<NCH>::U_RUN, Y2_PER_RUN = Geo<NCH>::Y2_PER_RUN;
+            constexpr int Y2_RUN = Geo<NCH>::Y2_RUN, Y3_PER_RUN = Geo<NCH>::Y3_PER_RUN;
+            // lane -> (chain slot, output, component): one chain uses all 64 lanes for 32 outputs,
+            // two chains put chain 0 on lanes 0-31 and chain 1 on lanes 32-63 (16 outputs each)
+            const int f2c = (NCH == 2) ? (lane >> 5) : 0;
+            const int f2o = (NCH == 2) ? ((lane >> 1) & 15) : half;
             while (n_u >= U_RUN) {
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    if (NCH == 2 && !((mask >> c) & 1u)) continue;
-                    const double *ub = (const double *)&lds.U[c][7 * half] + comp;
+                {
+                    const double *ub = (const double *)&lds.U[f2c][7 * f2o] + comp;
                     double acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NVX_T2; i++) acc += NVX_H2[i] * ub[2 * (52 - i)];
-                    ((double *)&lds.Y2[c][70 + n_y2 + half])[comp] = acc;
+                    if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds.Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
                 }
                 NVX_WAVE_LDS_FENCE();
-                // drop the 224 consumed inputs: keep 46 history + pending
-                const int keep = 46 + n_u - U_RUN;                  // <= 109
+                // drop the consumed inputs: keep 46 history + pending (<= 109 entries)
+                const int keep = 46 + n_u - U_RUN;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     double2 t0 = lds.U[c][U_RUN + lane];
-                    double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 48) ? lane : 47)];
+                    double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 45) ? lane : 44)];
                     NVX_WAVE_LDS_FENCE();
                     if (lane < keep) lds.U[c][lane] = t0;
                     if (lane + 64 < keep) lds.U[c][64 + lane] = t1;
                 }
                 NVX_WAVE_LDS_FENCE();
                 n_u -= U_RUN;
-                n_y2 += 32;
+                n_y2 += Y2_PER_RUN;
 
-                // ---- 7. FIR3 when 160 FIR2 outputs are pending ------------------
+                // ---- 7. FIR3 when a batch of FIR2 outputs is pending ----------------
                 if (n_y2 >= Y2_RUN) {
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) {
-                        if (NCH == 2 && !((mask >> c) & 1u)) continue;
-                        const int ch = (NCH == 1) ? chain_of_slot0 : c;
-                        const int p = half & (Y3_PER_RUN - 1);
-                        const double *yb = (const double *)&lds.Y2[c][10 * p] + comp;
+                    // lanes 0 .. 2*Y3_PER_RUN-1 hold chain 0 (output, component); with two chains the
+                    // next 2*Y3_PER_RUN lanes hold chain 1
+                    const int f3c = (NCH == 2) ? ((lane >> 4) & 1) : 0;
+                    const int f3o = half & (Y3_PER_RUN - 1);
+                    const bool f3live = lane < 2 * Y3_PER_RUN * NCH;
+                    {
+                        const int ch = (NCH == 1) ? chain_of_slot0 : f3c;
+                        const double *yb = (const double *)&lds.Y2[f3c][10 * f3o] + comp;
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
-                        if (lane < 2 * Y3_PER_RUN) {
-                            double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + p));
+                        if (f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
+                            double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + f3o));
                             out[comp] = acc;
                         }
                     }
                     NVX_WAVE_LDS_FENCE();
-                    const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101
+                    const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101 (one chain) / 85 (two chains)
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         double2 t0 = lds.Y2[c][Y2_RUN + lane];
-                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36)];   // keep3 - 64 <= 37
+                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36) * (NCH == 1) + ((lane < 21) ? lane : 20) * (NCH == 2)];
                         NVX_WAVE_LDS_FENCE();
                         if (lane < keep3) lds.Y2[c][lane] = t0;
                         if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
