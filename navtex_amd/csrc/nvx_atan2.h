@@ -12,9 +12,10 @@
  * Method: a = min(|x|,|y|), b = max(|x|,|y|), k = round(64 a/b), c = k/64;
  *   atan(a/b) = atan(c) + atan(z),  z = (a - c b) / (b + c a),  |z| <= ~1/127
  * with atan(c) from a 65-entry double-double table (tools/gen_atan_table.py),
- * z from exact products and one double-double division, atan(z) from its
- * Taylor series (first three terms in double-double).  Octant fix-ups with
- * double-double pi/2 and pi.  Special cases follow C99 Annex F (what glibc
+ * z from exact products, compensated sums and a quotient plus one correction
+ * quotient, atan(z) from its Taylor series with the cubic term carried as a
+ * (hi, lo) pair and the rest in double.  Octant fix-ups with double-double
+ * pi/2 and pi.  Special cases follow C99 Annex F (what glibc
  * implements): signed zeros, infinities, NaN.
  *
  * Compile with -ffp-contract=off: the error-free transformations below must
@@ -69,30 +70,6 @@ NVX_HD nvx_dd nvx_dd_add(nvx_dd a, nvx_dd b)
     return nvx_fast_two_sum(s.hi, s.lo);
 }
 NVX_HD nvx_dd nvx_dd_neg(nvx_dd a) { nvx_dd r = { -a.hi, -a.lo }; return r; }
-NVX_HD nvx_dd nvx_dd_mul(nvx_dd a, nvx_dd b)
-{
-    nvx_dd p = nvx_two_prod(a.hi, b.hi);
-    p.lo += a.hi * b.lo + a.lo * b.hi;
-    return nvx_fast_two_sum(p.hi, p.lo);
-}
-NVX_HD nvx_dd nvx_dd_mul_d(nvx_dd a, double b)
-{
-    nvx_dd p = nvx_two_prod(a.hi, b);
-    p.lo += a.lo * b;
-    return nvx_fast_two_sum(p.hi, p.lo);
-}
-NVX_HD nvx_dd nvx_dd_div(nvx_dd a, nvx_dd b)
-{
-    double q1 = a.hi / b.hi;
-    nvx_dd r = nvx_dd_add(a, nvx_dd_neg(nvx_dd_mul_d(b, q1)));
-    double q2 = r.hi / b.hi;
-    r = nvx_dd_add(r, nvx_dd_neg(nvx_dd_mul_d(b, q2)));
-    double q3 = r.hi / b.hi;
-    nvx_dd q = nvx_fast_two_sum(q1, q2);
-    q.lo += q3;
-    return nvx_fast_two_sum(q.hi, q.lo);
-}
-
 NVX_HD uint64_t nvx_bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 NVX_HD double nvx_from_bits(uint64_t u) { double v; memcpy(&v, &u, 8); return v; }
 
@@ -151,27 +128,32 @@ NVX_HD double nvx_atan2(double y, double x)
         double t = a / b;
         int k = (int)(t * 64.0 + 0.5);
         double c = (double)k * 0.015625;
-        /* num = a - c*b, den = b + c*a, both in double-double                 */
+        /* z = (a - c b) / (b + c a) to ~2^-100: exact products, compensated sums,
+         * one quotient and one correction quotient                            */
         nvx_dd pcb = nvx_two_prod(c, b), pca = nvx_two_prod(c, a);
-        nvx_dd ad = { a, 0.0 }, bd = { b, 0.0 };
-        nvx_dd num = nvx_dd_add(ad, nvx_dd_neg(pcb));
-        nvx_dd den = nvx_dd_add(bd, pca);
-        nvx_dd z = nvx_dd_div(num, den);
-        /* atan z = z - z^3/3 + z^5/5 - z^7/7 + z^9/9 - z^11/11 + z^13/13 ...  */
-        nvx_dd z2 = nvx_dd_mul(z, z);
-        double w = z2.hi;
-        /* tail (terms z^8 .. z^16 of the bracket) in double                   */
-        double tail = w * w * w * w * (1.0 / 9.0 - w * (1.0 / 11.0 - w * (1.0 / 13.0 - w * (1.0 / 15.0 - w * (1.0 / 17.0)))));
-        /* bracket = 1 - z2/3 + z2^2/5 - z2^3/7 + tail, head in double-double   */
-        nvx_dd third = { NVX_THIRD_HI, NVX_THIRD_LO }, fifth = { NVX_FIFTH_HI, NVX_FIFTH_LO },
-               seventh = { NVX_SEVENTH_HI, NVX_SEVENTH_LO };
-        nvx_dd tl = { tail, 0.0 };
-        nvx_dd p = nvx_dd_add(nvx_dd_neg(nvx_dd_mul(z2, seventh)), fifth);     /* 1/5 - z2/7        */
-        p = nvx_dd_add(nvx_dd_neg(nvx_dd_mul(z2, p)), third);                  /* 1/3 - z2(..)      */
-        p = nvx_dd_mul(z2, p);                                                 /* z2/3 - z2^2/5 +.. */
-        p = nvx_dd_add(nvx_dd_neg(p), tl);                                     /* -(..) + tail      */
-        nvx_dd corr = nvx_dd_mul(z, p);                                        /* z * (bracket - 1) */
-        nvx_dd atz = nvx_dd_add(z, corr);
+        nvx_dd n1 = nvx_two_sum(a, -pcb.hi);
+        nvx_dd num = nvx_fast_two_sum(n1.hi, n1.lo - pcb.lo);
+        nvx_dd d1 = nvx_two_sum(b, pca.hi);
+        nvx_dd den = nvx_fast_two_sum(d1.hi, d1.lo + pca.lo);
+        double q1 = num.hi / den.hi;
+        double r1 = __builtin_fma(-q1, den.hi, num.hi);       /* exact remainder of the leading parts */
+        r1 += num.lo - q1 * den.lo;
+        double q2 = r1 / den.hi;
+        nvx_dd z = nvx_fast_two_sum(q1, q2);
+        /* atan z = z - z^3/3 + z^5/5 - ...,  |z| <= 1/127.
+         * The cubic term is <= 2^-15.6 of the result, so it needs ~2^-60 relative
+         * accuracy: w = z^2 and z*w/3 are carried as (hi, lo) pairs.  Everything from
+         * z^5 on is below 2^-30 of the result and plain double suffices.       */
+        nvx_dd w = nvx_two_prod(z.hi, z.hi);
+        w.lo += 2.0 * z.hi * z.lo;
+        nvx_dd zw = nvx_two_prod(z.hi, w.hi);
+        zw.lo += z.hi * w.lo;
+        nvx_dd cub = nvx_two_prod(zw.hi, NVX_THIRD_HI);
+        cub.lo += zw.hi * NVX_THIRD_LO + zw.lo * NVX_THIRD_HI;
+        const double w1 = w.hi;
+        const double tail = z.hi * (w1 * w1 * (1.0 / 5.0 - w1 * (1.0 / 7.0 - w1 * (1.0 / 9.0 - w1 * (1.0 / 11.0 - w1 * (1.0 / 13.0))))));
+        nvx_dd s3 = nvx_two_sum(z.hi, -cub.hi);
+        nvx_dd atz = nvx_fast_two_sum(s3.hi, s3.lo + ((z.lo - cub.lo) + tail));
         nvx_dd atc = { NVX_ATAN_HI[k], NVX_ATAN_LO[k] };
         res = nvx_dd_add(atc, atz);
     }
