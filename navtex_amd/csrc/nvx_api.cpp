@@ -110,6 +110,7 @@ struct nvx_handle {
     // host
     std::vector<uint8_t> masks;
     std::vector<Slot> slots;
+    std::vector<struct SinkCtx *> sinks;   // user pointers handed to the per-slot character layers
     std::mutex mu;
     // push mode staging: two pinned sets [n_streams][stage_cap] of packed IQ words
     uint32_t *h_stage[2] = { nullptr, nullptr };
@@ -177,14 +178,13 @@ static void free_handle(nvx_handle *h)
     for (auto &s : h->slots) {
         if (s.sitor) nvx_sitor_free(s.sitor);
     }
+    for (auto *c : h->sinks) delete c;
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->stream2) hipStreamDestroy(h->stream2);
     delete h;
 }
 
 extern "C" void nvx_destroy(nvx_handle *h) { free_handle(h); }
-
-static std::vector<SinkCtx *> &sink_pool() { static std::vector<SinkCtx *> p; return p; }
 
 extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
 {
@@ -215,7 +215,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
             sl.label = cfg->labels ? cfg->labels[2 * s + c] : (c == 0 ? 518 : 490);
             if (sl.active && cfg->char_layer) {
                 SinkCtx *ctx = new SinkCtx{ h, s, 2 * s + c };
-                sink_pool().push_back(ctx);         // lives as long as the process (tiny)
+                h->sinks.push_back(ctx);
                 sl.sitor = nvx_sitor_new(sl.label, sitor_sink, ctx);
             }
         }

@@ -281,3 +281,13 @@ def test_live_capture_overrun_is_counted_not_silent(nv, oracle):
         got = p.bits(0, 0)
         # the GPU only runs whole frames: the oracle may be a few bits ahead at the very end
         assert want.startswith(got) and len(want) - len(got) <= 40 and len(got) > 200
+
+
+def test_empty_and_tiny_pushes(nv):
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=1, push_mode=True) as p:
+        p.push(0, np.zeros((0, 2), dtype=np.int16))      # empty push is a no-op
+        p.flush()
+        assert p.bits(0, 0) == "" and p.bit_count(0, 0) == 0
+        p.push(0, np.zeros((1, 2), dtype=np.int16))      # less than a frame: staged, nothing launched
+        p.flush()
+        assert p.bits(0, 0) == ""

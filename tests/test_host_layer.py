@@ -104,3 +104,14 @@ def test_generator_offset_equals_slice(nv):
     st2, _ = signals.stream_params(nv, 5, nv.RATE_IN)
     a = nv.synth_host(st2, nv.RATE_IN, 6000)
     assert a.shape == (6000, 2) and np.abs(a).max() < 12000
+
+
+def test_empty_inputs(nv):
+    s = nv.Sitor(518, trace=True)
+    s.feed("")
+    assert s.messages == [] and s.trace() == ""
+    bits = nv.sitor_encode("", 2)                          # phasing pairs + the three closing idle pairs only
+    assert len(bits) == (2 + 3) * 14
+    st = nv.make_stream([], seed=3, noise_amp=0)
+    assert np.array_equal(nv.synth_host(st, nv.RATE_IN, 100), np.zeros((100, 2), dtype=np.int16))
+    assert nv.synth_host(st, nv.RATE_IN, 0).shape == (0, 2)
