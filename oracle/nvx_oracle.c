@@ -335,6 +335,26 @@ int nvxo_dec_push(nvxo_dec *d, double sampleI, double sampleQ)      /* decoder.C
     return bd_sample(d, sampleI, sampleQ);
 }
 
+size_t nvxo_decode_with(const double *y3, size_t n3, char *bits_out, nvxo_atan2_fn fn, size_t *dphi_mismatch)
+{
+    nvxo_dec d; nvxo_dec_init(&d);
+    size_t nb = 0, mism = 0;
+    for (size_t k = 0; k < n3; k++) {
+        const double sampleI = y3[2 * k], sampleQ = y3[2 * k + 1];
+        const double prodReal = sampleI * d.prevI + sampleQ * d.prevQ;       /* decoder.C:48-49 */
+        const double prodImg  = sampleQ * d.prevI - sampleI * d.prevQ;
+        const double ref = atan2(prodImg, prodReal);
+        const double result = fn ? fn(prodImg, prodReal) : ref;
+        if (memcmp(&ref, &result, 8)) mism++;
+        d.prevI = sampleI; d.prevQ = sampleQ;
+        bs_sample(&d, result);
+        int b = bd_sample(&d, sampleI, sampleQ);
+        if (b) bits_out[nb++] = (char)b;
+    }
+    if (dphi_mismatch) *dphi_mismatch = mism;
+    return nb;
+}
+
 size_t nvxo_decode(const double *y3, size_t n3, char *bits_out, double *dphi_out)
 {
     nvxo_dec d; nvxo_dec_init(&d);

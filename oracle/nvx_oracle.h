@@ -77,6 +77,11 @@ int  nvxo_dec_push(nvxo_dec *d, double I, double Q);
 /* whole-array convenience: bits_out must hold n3 chars; returns number of bits */
 size_t nvxo_decode(const double *y3, size_t n3, char *bits_out, double *dphi_out);
 void nvxo_bitfilter_table(float fR[5], float fI[5]);
+/* test hook: same as nvxo_decode but with the discriminator's atan2 supplied by the caller
+ * (NULL = libm).  Used to measure whether replacing glibc's atan2 by another one that
+ * differs in the last bit ever changes a decoded bit.                                    */
+typedef double (*nvxo_atan2_fn)(double, double);
+size_t nvxo_decode_with(const double *y3, size_t n3, char *bits_out, nvxo_atan2_fn fn, size_t *dphi_mismatch);
 
 /* ---- SITOR-B character layer (nav_b_sm.h / nav_b_sm.C) -------------------- */
 typedef void (*nvxo_msg_cb)(void *user, const char *bbbb, const char *message, int freq);

@@ -34,7 +34,7 @@ for name, res, args in [
     ("nvxo_fir1", _sz, [_vp, _sz, _vp]), ("nvxo_mix", None, [_vp, _sz, _i, _vp]),
     ("nvxo_fir2", _sz, [_vp, _sz, _vp]), ("nvxo_fir3", _sz, [_vp, _sz, _vp]),
     ("nvxo_mixer_table", None, [_vp, _vp]), ("nvxo_bitfilter_table", None, [_vp, _vp]),
-    ("nvxo_decode", _sz, [_vp, _sz, _vp, _vp]),
+    ("nvxo_decode", _sz, [_vp, _sz, _vp, _vp]), ("nvxo_decode_with", _sz, [_vp, _sz, _vp, _vp, C.POINTER(_sz)]),
     ("nvxo_sm_new", _vp, [_i, MSG_FN, _vp]), ("nvxo_sm_free", None, [_vp]), ("nvxo_sm_bit", None, [_vp, C.c_char]),
     ("nvxo_sm_trace", C.c_char_p, [_vp, C.POINTER(_sz)]),
     ("nvxo_pipe_new", _vp, [_i, _i, _i, MSG_FN, _vp]), ("nvxo_pipe_free", None, [_vp]),
@@ -105,6 +105,16 @@ def decode(y3: np.ndarray) -> Tuple[str, np.ndarray]:
     dphi = np.empty(y3.shape[0])
     n = L.nvxo_decode(_p(y3), y3.shape[0], bits, _p(dphi))
     return bits.raw[:n].decode("ascii"), dphi
+
+
+def decode_with(y3: np.ndarray, atan2_fn_ptr) -> Tuple[str, int]:
+    """Decoder restatement with a caller-supplied atan2 (C function pointer, or None for libm).
+    Returns (bits, number of samples whose delta-phi differed from libm's)."""
+    y3 = np.ascontiguousarray(y3, dtype=np.float64).reshape(-1, 2)
+    bits = C.create_string_buffer(y3.shape[0] + 1)
+    mism = _sz(0)
+    n = L.nvxo_decode_with(_p(y3), y3.shape[0], bits, atan2_fn_ptr, C.byref(mism))
+    return bits.raw[:n].decode("ascii"), mism.value
 
 
 def mixer_table() -> Tuple[np.ndarray, np.ndarray]:
