@@ -589,9 +589,9 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     // time: byte stores would sit in front of every prefetched load in the in-order
     // vmcnt queue
     unsigned *bits = (unsigned *)(a.bits + (size_t)slot * a.bits_cap);
-    const int cap_bits = a.bits_cap * 8;
-    int nbits = 0;
-    unsigned acc = 0;
+    const int cap_words = a.bits_cap / 4;
+    unsigned long long acc = 0;                   // pending bits, LSB first
+    int nacc = 0, nwords = 0;                     // bits pending in acc (< 64), words already stored
     const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
     const unsigned short *words = a.words + slot;
     unsigned wq[4];
@@ -626,17 +626,21 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
                 const bool start = (phase < 0) && synced && (((k + 1) % 9) == sync_off);
                 phase = start ? 0 : ((phase >= 0) ? phase + 1 : phase);
                 const bool decide = phase == 7;
-                acc |= decide ? (((w >> k) & 1u) << (nbits & 31)) : 0u;
-                nbits += decide ? 1 : 0;
-                if (decide && (nbits & 31) == 0) { if (nbits <= cap_bits) bits[(nbits >> 5) - 1] = acc; acc = 0; }
+                acc |= decide ? ((unsigned long long)((w >> k) & 1u) << nacc) : 0ull;
+                nacc += decide ? 1 : 0;
                 phase = decide ? -1 : phase;
                 sync_off = decide ? next_sync_off : sync_off;
             }
         }
+        // at most 5 bits per 4 periods: one store check per group keeps the sample steps branch-free
+        if (nacc >= 32) {
+            if (nwords < cap_words) bits[nwords] = (unsigned)acc;
+            nwords++; acc >>= 32; nacc -= 32;
+        }
     }
-    if ((nbits & 31) != 0 && nbits <= cap_bits) bits[nbits >> 5] = acc;
+    if (nacc > 0 && nwords < cap_words) bits[nwords] = (unsigned)acc;
 
-    a.nbits[slot] = nbits;
+    a.nbits[slot] = nwords * 32 + nacc;
     SI(DI_SYNCED) = synced; SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off;
     SI(DI_PHASE) = phase; SI(DI_PREV_OFFSET) = prev_offset;
 #undef SI
