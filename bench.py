@@ -54,6 +54,33 @@ def parse():
     return ap.parse_args()
 
 
+def reference_check(ob, raw_stream):
+    """Strawman guard: the reference ITSELF (oracle/_ref/ref_bits, built from /root/reference in the
+    build container and shipped as a binary) against the port, one thread each, on the same 252 kS/s input
+    (the stream's stage-0 output; the reference always runs both chains).  None when the binary is absent."""
+    import subprocess, tempfile
+    exe = ROOT / "oracle" / "_ref" / "ref_bits"
+    if not exe.exists():
+        return None
+    try:
+        iq252 = ob.stage0(raw_stream)[: 252000 * 4]
+        with tempfile.TemporaryDirectory() as td:
+            f = Path(td) / "in.bin"; iq252.tofile(f)
+            t0 = time.perf_counter()
+            subprocess.run([str(exe), str(f), str(Path(td) / "o")], check=True, stdout=subprocess.DEVNULL, timeout=120)
+            t_ref = time.perf_counter() - t0
+            ref518 = (Path(td) / "o.bits518.bin").read_bytes().decode()
+        t0 = time.perf_counter()
+        p = ob.Pipe(chain_mask=3, charlayer=False); p.push(iq252)
+        t_port = time.perf_counter() - t0
+        return {"input": f"{iq252.shape[0] / 1e6:.2f} M samples at 252 kS/s, both chains, 1 thread",
+                "reference_msamples_per_s": round(iq252.shape[0] / t_ref / 1e6, 1),
+                "port_msamples_per_s": round(iq252.shape[0] / t_port / 1e6, 1),
+                "bits_identical": p.bits(0) == ref518}
+    except Exception as e:                      # never let the guard break the benchmark line
+        return {"error": str(e)[:200]}
+
+
 def wideband_streams(nv, signals, rank, W, n_phasing=40):
     """W wideband streams: a carrier at k*252 kHz +-14 kHz for k = 0..7, each with its own text."""
     out = []
@@ -265,6 +292,7 @@ def main():
                           f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
                 "seconds": round(sN, 2),
             }
+            cpu["reference_check"] = reference_check(ob, sample[0])
         else:
             cpu_bits = []
             for s in range(n_cs if world == 1 else min(n_cs, 4)):
