@@ -178,3 +178,40 @@ def test_long_run_state_carry(nv, oracle):
         p.flush()
         assert p.bits(0, 0) == ref.bits(0) and len(ref.bits(0)) > 9900
         assert [(f, b, m) for (_s, f, b, m) in p.messages] == ref.messages and len(ref.messages) >= 1
+
+
+def test_full_size_properties_config3(nv, oracle):
+    """BASELINE configs[3] at full size (4096 streams x 2.016 MS/s, 12 frames = 127 GB in HBM), checked
+    through size-independent properties: run-to-run determinism, identical streams decode identically,
+    a different launch partition changes nothing, and a sample of streams matches the oracle bit for bit."""
+    S, F = 4096, 12
+    pitch = F * nv.FRAME_RAW
+    try:
+        buf = nv.DeviceBuffer(S * pitch * 4)
+    except nv.NvxError:
+        pytest.skip("not enough device memory for the full-size batch")
+    streams = [signals.stream_params(nv, s, nv.RATE_RAW)[0] for s in range(S)]
+    twins = [(5, 4000), (77, 2049), (1023, 1024)]
+    for a, b in twins:
+        streams[b] = streams[a]
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F, char_layer=False) as p:
+        runs = []
+        for plan in ([12], [12], [5, 7]):
+            p.reset()
+            f0 = 0
+            for k in plan:
+                p.process_resident(buf, pitch, f0, k); f0 += k
+            p.fetch()
+            runs.append([p.bits(s, 0) for s in range(S)])
+        assert runs[0] == runs[1], "two identical runs differ"
+        assert runs[0] == runs[2], "launch partition changed the result"
+        for a, b in twins:
+            assert runs[0][a] == runs[0][b]
+        assert min(len(b) for b in runs[0]) > 300
+        for s in (0, 1, 4095, 2048, 3333):
+            iq = buf.download(pitch * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+            ref = oracle.Pipe(chain_mask=1, charlayer=False)
+            ref.push_raw(iq)
+            assert runs[0][s] == ref.bits(0), f"stream {s}"
+    buf.free()
