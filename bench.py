@@ -105,15 +105,16 @@ def run_wideband(args, nv, signals, torch, dist, rank, world, device, backend):
     n_raw, n_sub = F * nv.FRAME_RAW, F * nv.FRAME_IN
     t0 = time.time()
     raw = nv.DeviceBuffer(W * n_raw * 4, device=device)
-    sub = nv.DeviceBuffer(8 * W * n_sub * 4, device=device)
+    sub = None
     nv.synth_device(wideband_streams(nv, signals, rank, W), nv.RATE_RAW, n_raw, raw, n_raw)
     t_gen = time.time() - t0
-    pipe = nv.Pipeline(n_streams=8 * W, raw_rate=False, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device)
-    st = pipe.hip_stream
+    # wideband handle: channeliser (own stream, double-buffered sub-bands) + 252 kS/s path; the channeliser
+    # of step k+1 overlaps the cascade of step k
+    pipe = nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device)
+    del sub
 
     def step():
-        nv.channelise(raw, n_raw, 0, W, n_sub, sub, n_sub, hip_stream=st)
-        pipe.process_resident(sub, n_sub, 0, F, hip_stream=st)
+        pipe.process_resident(raw, n_raw, 0, F)
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -183,7 +184,7 @@ def run_wideband(args, nv, signals, torch, dist, rank, world, device, backend):
             "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(t_gen, 1),
         }
         print(json.dumps(line), flush=True)
-    pipe.close(); raw.free(); sub.free()
+    pipe.close(); raw.free()
 
 
 def main():

@@ -138,8 +138,15 @@ typedef struct nvx_config {
     nvx_message_fn on_message;/* NULL: call add_message(bbbb, message, freq)               */
     void    *user;
     int      push_mode;       /* 1: allocate pinned staging for nvx_push_* (host input)    */
+    int      wideband;        /* 1: n_streams counts WIDEBAND inputs at 2.016 MS/s (raw_rate is  */
+                              /* ignored); each is channelised (section G) into 8 sub-bands that  */
+                              /* run through the 252 kS/s path.  Decoded stream index = 8*w + k   */
+                              /* (k = sub-band, centre k*252 kHz), so chain_masks / labels have   */
+                              /* 8*n_streams entries.                                             */
 } nvx_config;
 
+/* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the
+ * handle locked: they must not call back into the same handle.                                      */
 NVX_API void nvx_config_default(nvx_config *cfg);
 NVX_API int  nvx_create(const nvx_config *cfg, nvx_handle **out);
 NVX_API void nvx_destroy(nvx_handle *h);

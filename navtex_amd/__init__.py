@@ -145,14 +145,17 @@ class Pipeline:
 
     def __init__(self, n_streams: int = 1, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
                  chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None,
-                 max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0):
+                 max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0,
+                 wideband: bool = False):
         self.messages: List[Tuple[int, int, str, str]] = []          # (stream, freq, bbbb, text)
         cfg = N.Config()
         lib.nvx_config_default(C.byref(cfg))
         cfg.device, cfg.n_streams, cfg.raw_rate = device, n_streams, int(raw_rate)
         cfg.chain_mask, cfg.max_frames, cfg.char_layer, cfg.push_mode = chain_mask, max_frames, int(char_layer), int(push_mode)
+        cfg.wideband = int(wideband)
         if chain_masks is not None:
-            self._masks = (C.c_uint8 * n_streams)(*list(chain_masks))
+            chain_masks = list(chain_masks)
+            self._masks = (C.c_uint8 * len(chain_masks))(*chain_masks)
             cfg.chain_masks = self._masks
         if labels is not None:
             flat = [int(v) for pair in labels for v in pair]
@@ -161,7 +164,8 @@ class Pipeline:
         self._cb = N.MESSAGE_FN(lambda u, s, b, m, f: self.messages.append((s, f, b.decode("latin1"), m.decode("latin1"))))
         cfg.on_message = self._cb
         self.n_streams, self.raw_rate, self.max_frames, self.device = n_streams, bool(raw_rate), max_frames, device
-        self.frame = FRAME_RAW if raw_rate else FRAME_IN
+        self.wideband = bool(wideband)
+        self.frame = FRAME_RAW if (raw_rate or wideband) else FRAME_IN
         h = C.c_void_p()
         N.check(lib.nvx_create(C.byref(cfg), C.byref(h)), "nvx_create")
         self._h = h

@@ -29,6 +29,7 @@ class Config(C.Structure):
         ("device", C.c_int), ("n_streams", C.c_int), ("raw_rate", C.c_int), ("chain_mask", C.c_uint32),
         ("chain_masks", C.POINTER(C.c_uint8)), ("labels", C.POINTER(C.c_int)), ("max_frames", C.c_int),
         ("char_layer", C.c_int), ("on_message", MESSAGE_FN), ("user", C.c_void_p), ("push_mode", C.c_int),
+        ("wideband", C.c_int),
     ]
 
 

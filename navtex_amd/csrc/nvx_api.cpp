@@ -83,8 +83,17 @@ struct Result {                        // one in-flight launch's bit output
 
 struct nvx_handle {
     nvx_config cfg{};
-    int n_streams = 0, n_slots = 0, nch = 1;
+    int n_streams = 0, n_slots = 0, nch = 1;   // n_streams: 252 kS/s-path streams (8 per input in wideband mode)
+    int n_in = 0;                      // input streams the caller addresses (= n_streams unless wideband)
+    bool cascade_raw = false;          // the cascade kernel's RAW switch (never set in wideband mode)
     size_t frame_in = 0;               // complex input samples per frame at the input rate
+    // wideband mode: channeliser on stream3 into sub[b], overlapping the cascade of the previous launch
+    hipStream_t stream3 = nullptr;
+    uint32_t *d_sub[2] = { nullptr, nullptr };
+    uint32_t *d_whist[2] = { nullptr, nullptr };
+    hipEvent_t chan_done[2] = { nullptr, nullptr }, sub_free[2] = { nullptr, nullptr }, in_ready[2] = { nullptr, nullptr };
+    bool sub_busy[2] = { false, false };
+    uint64_t wide_launches = 0;
     int y3_cap = 0, bits_cap = 0;
     hipStream_t stream = nullptr;      // FIR cascade (or the caller's stream) and H2D staging
     hipStream_t stream2 = nullptr;     // demodulator + D2H of the bits: overlaps the next cascade launch
@@ -160,6 +169,13 @@ static void free_handle(nvx_handle *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->stream2) hipStreamSynchronize(h->stream2);
+    if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
+    for (int i = 0; i < 2; i++) {
+        hipFree(h->d_sub[i]); hipFree(h->d_whist[i]);
+        if (h->chan_done[i]) hipEventDestroy(h->chan_done[i]);
+        if (h->sub_free[i]) hipEventDestroy(h->sub_free[i]);
+        if (h->in_ready[i]) hipEventDestroy(h->in_ready[i]);
+    }
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
@@ -195,8 +211,11 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
 
     nvx_handle *h = new nvx_handle();
     h->cfg = *cfg;
-    h->n_streams = cfg->n_streams; h->n_slots = 2 * cfg->n_streams;
-    h->frame_in = cfg->raw_rate ? (size_t)NVX_FRAME_RAW : (size_t)NVX_FRAME_IN;
+    h->n_in = cfg->n_streams;
+    h->n_streams = cfg->wideband ? NVX_WB_SUBBANDS * cfg->n_streams : cfg->n_streams;
+    h->n_slots = 2 * h->n_streams;
+    h->cascade_raw = cfg->raw_rate && !cfg->wideband;
+    h->frame_in = (cfg->raw_rate || cfg->wideband) ? (size_t)NVX_FRAME_RAW : (size_t)NVX_FRAME_IN;
     h->y3_cap = cfg->max_frames * NVX_FRAME_Y3;
     // a bit needs >= 8 samples (the offset slews by at most 1 per bit); packed 8 bits per byte, whole words
     h->bits_cap = (((h->y3_cap / 8 + 8) + 31) / 32) * 4;
@@ -254,14 +273,24 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         for (int i = 0; i < 4; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
+    if (cfg->wideband) {
+        CR_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            CR_TRY(hipMalloc(&h->d_sub[i], (size_t)h->n_streams * cfg->max_frames * NVX_FRAME_IN * 4));
+            CR_TRY(hipMalloc(&h->d_whist[i], (size_t)h->n_in * 40 * 4));
+            CR_TRY(hipEventCreateWithFlags(&h->chan_done[i], hipEventDisableTiming));
+            CR_TRY(hipEventCreateWithFlags(&h->sub_free[i], hipEventDisableTiming));
+            CR_TRY(hipEventCreateWithFlags(&h->in_ready[i], hipEventDisableTiming));
+        }
+    }
     if (cfg->push_mode) {
         h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
         for (int i = 0; i < 2; i++) {
-            CR_TRY(hipHostMalloc((void **)&h->h_stage[i], (size_t)h->n_streams * h->stage_cap * 4, hipHostMallocDefault));
+            CR_TRY(hipHostMalloc((void **)&h->h_stage[i], (size_t)h->n_in * h->stage_cap * 4, hipHostMallocDefault));
             CR_TRY(hipEventCreateWithFlags(&h->stage_free[i], hipEventDisableTiming));
         }
-        CR_TRY(hipMalloc(&h->d_in, (size_t)h->n_streams * cfg->max_frames * h->frame_in * 4));
-        h->fill.assign(h->n_streams, 0);
+        CR_TRY(hipMalloc(&h->d_in, (size_t)h->n_in * cfg->max_frames * h->frame_in * 4));
+        h->fill.assign(h->n_in, 0);
     }
 #undef CR_TRY
     rc = nvx_reset(h);
@@ -283,6 +312,12 @@ extern "C" int nvx_reset(nvx_handle *h)
     h->collected = h->launched;
     h->g0 = 0;
     h->demod_pending[0] = h->demod_pending[1] = false;
+    if (h->stream3) {
+        HIP_TRY(hipStreamSynchronize(h->stream3));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_whist[i], 0, (size_t)h->n_in * 40 * 4, h->stream));
+        h->sub_busy[0] = h->sub_busy[1] = false;
+        h->wide_launches = 0;
+    }
     HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
@@ -299,12 +334,41 @@ extern "C" int nvx_reset(nvx_handle *h)
 }
 
 // launch cascade + demod over n_frames frames of [n_streams][pitch] packed IQ
-static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st)
+static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
+                         bool input_on_stream3 = false)
 {
     if (n_frames < 1 || n_frames > h->cfg.max_frames) { nvx_set_error("n_frames %d outside 1..max_frames %d", n_frames, h->cfg.max_frames); return NVX_ERR_ARG; }
     if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
     Result &r = h->res[h->launched % RESULT_SLOTS];
     if (r.pending) { int rc = collect_locked(h); if (rc != NVX_OK) return rc; }
+
+    const int wb = (int)(h->wide_launches & 1);
+    // Measured (profiles/r01, DESIGN.md tuning log): letting the channeliser of launch k+1 run beside the
+    // cascade of launch k (own stream, cascade grid capped at 8 waves per CU to leave LDS) LOSES: 22.2 vs
+    // 21.2 ms per step -- the capped cascade and the demodulator slow down by more than the 6 ms hidden.
+    // Default: channeliser in front of the cascade on the same stream.  NVX_WB_OVERLAP=1 re-enables it.
+    static const bool wb_overlap = getenv("NVX_WB_OVERLAP") && atoi(getenv("NVX_WB_OVERLAP")) == 1;
+    if (h->cfg.wideband) {
+        // channeliser into sub[wb]; sub[wb] was last read by the cascade two launches ago
+        hipStream_t s3 = (wb_overlap || input_on_stream3) ? h->stream3 : st;
+        // Input ordering.  Push path: the H2D copy was issued on stream3 itself.  Resident path on the
+        // handle's own stream: the caller made the data ready before the call (an event recorded on that
+        // stream would also capture the previous cascade and serialise the overlap away).  A caller-supplied
+        // stream may have produced the input, so the channeliser waits for it.
+        if (!input_on_stream3 && st != h->stream) {
+            HIP_TRY(hipEventRecord(h->in_ready[wb], st));
+            HIP_TRY(hipStreamWaitEvent(s3, h->in_ready[wb], 0));
+        }
+        if (h->sub_busy[wb]) HIP_TRY(hipStreamWaitEvent(s3, h->sub_free[wb], 0));
+        int rc = nvx_channelise_resident(h->cfg.device, d_iq, pitch, first_sample, h->n_in, (size_t)n_frames * NVX_FRAME_IN,
+                                         h->d_whist[wb], h->d_whist[wb ^ 1], h->d_sub[wb], (size_t)h->cfg.max_frames * NVX_FRAME_IN, 0, s3);
+        if (rc != NVX_OK) return rc;
+        HIP_TRY(hipEventRecord(h->chan_done[wb], s3));
+        HIP_TRY(hipStreamWaitEvent(st, h->chan_done[wb], 0));
+        d_iq = h->d_sub[wb];
+        pitch = (size_t)h->cfg.max_frames * NVX_FRAME_IN;
+        first_sample = 0;
+    }
 
     const int yb = (int)(h->launched & 1);              // y3 buffer of this launch
     // Measured (profiles/r01, DESIGN.md tuning log): running the demodulator on a second
@@ -317,6 +381,8 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
     ca.state = h->d_cstate; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
+    // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
+    ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : 0;
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
@@ -327,8 +393,9 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     if (h->demod_pending[yb]) HIP_TRY(hipStreamWaitEvent(st, h->demod_done[yb], 0));
     r.timed = h->timing;
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[0], st));
-    HIP_TRY(nvx_launch_cascade(&ca, h->cfg.raw_rate, h->nch, st));
+    HIP_TRY(nvx_launch_cascade(&ca, h->cascade_raw, h->nch, st));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
+    if (h->cfg.wideband) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
     HIP_TRY(hipMemcpyAsync(h->h_status + (h->launched % RESULT_SLOTS), h->d_ctrl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
     // demodulator + bit download on the second stream, behind this cascade only
@@ -507,15 +574,17 @@ static int submit_locked(nvx_handle *h)
     const size_t dpitch = (size_t)h->cfg.max_frames * h->frame_in;
     // the other staging set must have left the copy engine before it is refilled
     if (h->stage_busy[nxt]) { HIP_TRY(hipEventSynchronize(h->stage_free[nxt])); h->stage_busy[nxt] = false; }
-    // d_in is reused by every launch: stream order makes the previous kernels finish first
-    HIP_TRY(hipMemcpy2DAsync(h->d_in, dpitch * 4, h->h_stage[cur], h->stage_cap * 4, take * 4, (size_t)h->n_streams,
-                             hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipEventRecord(h->stage_free[cur], h->stream));
+    // d_in is reused by every launch: stream order makes its previous reader finish first (the cascade on
+    // h->stream, or in wideband mode the channeliser on stream3, which is why the copy goes there)
+    hipStream_t cs = h->cfg.wideband ? h->stream3 : h->stream;
+    HIP_TRY(hipMemcpy2DAsync(h->d_in, dpitch * 4, h->h_stage[cur], h->stage_cap * 4, take * 4, (size_t)h->n_in,
+                             hipMemcpyHostToDevice, cs));
+    HIP_TRY(hipEventRecord(h->stage_free[cur], cs));
     h->stage_busy[cur] = true;
-    int rc = launch_locked(h, h->d_in, dpitch, 0, frames, h->stream);
+    int rc = launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, h->cfg.wideband != 0);
     if (rc != NVX_OK) return rc;
     // carry what was not submitted over to the other set
-    for (int s = 0; s < h->n_streams; s++) {
+    for (int s = 0; s < h->n_in; s++) {
         size_t rest = h->fill[s] - take;
         if (rest) memcpy(h->h_stage[nxt] + (size_t)s * h->stage_cap, h->h_stage[cur] + (size_t)s * h->stage_cap + take, rest * 4);
         h->fill[s] = rest;
@@ -527,7 +596,7 @@ static int submit_locked(nvx_handle *h)
 template <typename F>
 static int push_common(nvx_handle *h, int stream, size_t n, F copy_in)
 {
-    if (!h || stream < 0 || stream >= h->n_streams) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -724,7 +793,7 @@ extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
     if (!h->cfg.push_mode) { nvx_set_error("nvx_decode_wav: handle needs push_mode"); return NVX_ERR_STATE; }
     nvx_wav *w = nvx_wav_open(filename, NVX_WAV_OPEN_READ);
     if (!w) { nvx_set_error("nvx_decode_wav: %s", nvx_wav_err()); return NVX_ERR_IO; }
-    const uint32_t want = h->cfg.raw_rate ? NVX_RATE_RAW : NVX_RATE_IN;
+    const uint32_t want = (h->cfg.raw_rate || h->cfg.wideband) ? NVX_RATE_RAW : NVX_RATE_IN;
     if (nvx_wav_get_num_channels(w) != 2 || nvx_wav_get_sample_size(w) != 2 || nvx_wav_get_format(w) != 1 ||
         nvx_wav_get_sample_rate(w) != want) {
         nvx_set_error("nvx_decode_wav: need 2-channel 16-bit PCM at %u Hz (capt_sched.c:91-95)", want);
@@ -873,11 +942,11 @@ static void capture_consumer(nvx_capture *c)
 
 extern "C" int nvx_capture_start(nvx_handle *h, int stream, double ring_seconds, nvx_capture **out)
 {
-    if (!h || !out || stream < 0 || stream >= h->n_streams || !(ring_seconds > 0)) { nvx_set_error("nvx_capture_start: bad argument"); return NVX_ERR_ARG; }
+    if (!h || !out || stream < 0 || stream >= h->n_in || !(ring_seconds > 0)) { nvx_set_error("nvx_capture_start: bad argument"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_capture_start: handle needs push_mode"); return NVX_ERR_STATE; }
     nvx_capture *c = new nvx_capture();
     c->h = h; c->stream = stream;
-    const double rate = h->cfg.raw_rate ? (double)NVX_RATE_RAW : (double)NVX_RATE_IN;
+    const double rate = (h->cfg.raw_rate || h->cfg.wideband) ? (double)NVX_RATE_RAW : (double)NVX_RATE_IN;
     c->cap = (size_t)(ring_seconds * rate);                              // capt_sched.c:443: rate * seconds
     if (c->cap < 16) c->cap = 16;
     c->ring.assign(2 * c->cap, 0);

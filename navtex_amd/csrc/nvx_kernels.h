@@ -31,6 +31,7 @@ typedef struct {
     int *queue;                /* NVX_CASCADE_CTRL_INTS control ints followed by ...   */
     int *status;               /* = queue + 1                                          */
     int *done;                 /* = queue + 2: frames completed per stream             */
+    int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid      */
 } nvx_cascade_args;
 
 typedef struct {

@@ -796,8 +796,8 @@ template <bool RAW, int NCH, int PFD, bool NT>
 static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
 {
     // persistent grid: as many single-wave workgroups as the chip holds at once
-    static int resident = 0;
-    if (!resident) {
+    static int n_cus = 0, fit_per_cu = 0;
+    if (!n_cus) {
         int dev = 0, cus = 0, per_cu = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -805,8 +805,12 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
         if (e != hipSuccess) return e;
         const int cap = env_int("NVX_WAVES_PER_CU", 0);
         if (cap > 0 && cap < per_cu) per_cu = cap;
-        resident = cus * (per_cu > 0 ? per_cu : 1);
+        fit_per_cu = per_cu > 0 ? per_cu : 1;
+        n_cus = cus;
     }
+    int per_cu = fit_per_cu;
+    if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;
+    const int resident = n_cus * per_cu;
     const long long units = (long long)a->n_streams * a->n_frames;
     const unsigned grid = (unsigned)(units < resident ? units : resident);
     hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, *a);

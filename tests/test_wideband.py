@@ -132,4 +132,27 @@ def test_sixteen_carriers_from_one_wideband_stream(nv, oracle):
             for c, f in ((0, 518), (1, 490)):
                 assert p.bits(k, c) == ref.bits(c), f"band {k} chain {c}"
                 assert got[(k, f)] == (f"W{chr(65 + k)}{k}{c}", texts[(k, c)]), f"band {k} chain {c}"
+    # the same through the wideband handle mode: three launches (history ping-pong, channeliser of
+    # launch k+1 overlapping the cascade of launch k), then once more through the host-fed push path
+    wl = [[1000 * (k + 1) + 518, 1000 * (k + 1) + 490] for k in range(8)]
+    with nv.Pipeline(n_streams=1, wideband=True, chain_mask=3, labels=wl, max_frames=12) as p:
+        for f0 in (0, 12, 24):
+            p.process_resident(d_raw, n, f0, 12)
+        p.fetch()
+        msgs = {(s, f % 1000): (b, m) for (s, f, b, m) in p.messages}
+        for k in range(8):
+            ref = oracle.Pipe(chain_mask=3, charlayer=False)
+            ref.push(sub[k])
+            for c, f in ((0, 518), (1, 490)):
+                assert p.bits(k, c) == ref.bits(c), f"wideband handle: band {k} chain {c}"
+                assert msgs[(k, f)] == (f"W{chr(65 + k)}{k}{c}", texts[(k, c)])
+        resident_bits = [p.bits(k, c) for k in range(8) for c in (0, 1)]
+    with nv.Pipeline(n_streams=1, wideband=True, chain_mask=3, labels=wl, max_frames=5, push_mode=True, char_layer=False) as p:
+        rng = np.random.default_rng(2)
+        pos = 0
+        while pos < n:
+            m = int(min(n - pos, rng.integers(1000, 3 * nv.FRAME_RAW)))
+            p.push(0, raw[pos:pos + m]); pos += m
+        p.flush()
+        assert [p.bits(k, c) for k in range(8) for c in (0, 1)] == resident_bits
     d_raw.free(); d_sub.free()
