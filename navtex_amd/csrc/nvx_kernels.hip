@@ -1,28 +1,32 @@
 // nvx_kernels.hip -- gfx950 kernels of the NAVTEX receive path.
 //
-//   nvx_fir_cascade<RAW, NCH>   int16 IQ in HBM -> 900 S/s complex fp64 per chain
+//   nvx_fir_cascade<RAW, NCH, PFD, NT>   int16 IQ in HBM -> 900 S/s complex fp64 per chain
 //        stage 0 (/8 integer, build-owned, RAW only)
 //        FIR1 37 taps /4        receiver/fir1cpp.C:80-136
 //        mixer +-14 kHz         receiver/fir2cpp.C:112-128
 //        FIR2 47 taps /7        receiver/fir2cpp.C:131-215
 //        FIR3 71 taps /10       receiver/fir3cpp.C:22-60
-//   nvx_demod_front + nvx_demod_fsm   900 S/s -> 'B'/'Y' bits
+//   nvx_demod_front + nvx_demod_fsm      900 S/s -> 'B'/'Y' bits
 //        discriminator          receiver/decoder.C:42-59
 //        bit-timing filter      receiver/decoder.C:142-255
 //        mark/space decision    receiver/decoder.C:73-137
+//   nvx_channelise              wideband front-end: 2.016 MS/s -> 8 x 252 kS/s (no reference counterpart)
 //   nvx_synth_kernel            deterministic CPFSK test source (no reference counterpart)
 //
 // Arithmetic contract (what makes results bit-identical to the reference's
 // x86-64 build): every FIR output is accumulated by ONE lane, acc = 0.0 then
 // acc = acc + h[i]*x in tap order, product and sum rounded separately (this
-// file is compiled with -ffp-contract=off; check the ISA for v_fma_f64: there
-// must be none outside nvx_atan2), I and Q independently, fp64 throughout.
+// file is compiled with -ffp-contract=off; the only v_fma_f64 in the ISA are
+// the explicit error-free transformations of nvx_atan2 and the expansion of
+// IEEE division), I and Q independently, fp64 throughout.
 //
 // Design of the cascade kernel (HBM-read bound; no MFMA -- 1-D decimating
 // convolutions):
-//   * one 64-lane wavefront per IQ stream walks that stream through time, so
-//     every input byte is read from HBM exactly once and no halo is re-read;
-//     filter histories live in LDS between passes and in HBM between launches;
+//   * a persistent grid of single-wave workgroups pulls work units (one frame
+//     of one stream) from an atomic queue; every input byte is read from HBM
+//     exactly once, no halo is re-read; filter histories live in LDS between
+//     passes and travel between units / launches through a state block in HBM
+//     (agent-scope release / acquire, see the comment above the kernel);
 //   * a pass = 64 FIR1 outputs = 256 samples @252 kS/s = 2048 raw samples =
 //     8 KiB: eight fully coalesced 1-KiB global_load_dwordx4 per wave, issued
 //     one pass ahead into registers (prefetch) so HBM latency hides behind the
@@ -32,11 +36,10 @@
 //     to fp64 and writes it to the LDS window;
 //   * the 252 kS/s window is kept polyphase-split (4 arrays of {I,Q} doubles)
 //     so that lane k's tap reads are consecutive 16-byte words: every
-//     ds_read_b128 / ds_write_b64 below is bank-conflict free;
-//   * FIR2 runs when 224 mixer outputs are buffered (32 outputs x {I,Q} = 64
-//     lanes), FIR3 when 160 FIR2 outputs are buffered (16 outputs x {I,Q});
-//   * a launch covers whole frames of 32 bit periods = 315 passes = 90 FIR2
-//     runs = 18 FIR3 runs, after which every decimation counter, the mixer
+//     ds_read_b128 / ds_write_b64 of FIR1 / stage 0 is bank-conflict free;
+//   * FIR2 and FIR3 run on batches of pending outputs sized to fill the wave
+//     (struct Geo below); a frame of 32 bit periods = 315 passes is a whole
+//     number of every batch, after which every decimation counter, the mixer
 //     index and all LDS fill levels are back at zero: the carried state is
 //     just the three filter histories.
 #include <hip/hip_runtime.h>
@@ -59,8 +62,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vect
 // ------------------------------------------------------------------ LDS map
 // X: four polyphase arrays of 74 double2 (9 history + 64 new + 1 pad; the pad
 //    makes the array stride = 8 banks mod 32 so the stage-0 writes spread)
-// U[c]:  mixer output buffer, 46 history + up to 224+63 pending  (336 double2)
-// Y2[c]: FIR2 output buffer, 70 history + up to 160+31 pending  (264 double2)
+// U[c]:  mixer output buffer, 46 history + pending (batch + up to 63)
+// Y2[c]: FIR2 output buffer, 70 history + pending (batch + one FIR2 run - 1)
 // MIX:   9 + 9 doubles
 #define XS 74
 #define X_ENTRIES (4 * XS)
