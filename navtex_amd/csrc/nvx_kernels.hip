@@ -155,6 +155,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 {
     __shared__ CascadeLds<NCH> lds;
     const int lane = threadIdx.x;
+    const bool EARLY = a.early_reload != 0;          // wave-uniform launch option (A/B switch)
 
     if (lane < NVX_MIX_N) {
         // constant-index selects keep the tables out of scratch
@@ -244,8 +245,14 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
             if (RAW) {
+                // A/B option (off): request each 1-KiB load register again (for pass + PFD) as soon as its own
+                // stage-0 sums are taken.  Keeps 8 KiB in flight almost continuously -- and measured 2-3 % slower
+                const bool more = pass + PFD < NVX_PASSES_PER_FRAME;
 #pragma unroll
-                for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], sel_mine, sel_other);   // +8 double2 entries per load
+                for (int j = 0; j < 8; j++) {
+                    xw[j * 16] = stage0_component(pf[j], sel_mine, sel_other);   // +8 double2 entries per load
+                    if (EARLY && more) pf[j] = NT ? __builtin_nontemporal_load(nxt + 64 * j) : nxt[64 * j];
+                }
             } else {
                 // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
                 const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 }
             }
             // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
-            if (pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
+            if (!(RAW && EARLY) && pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
 
@@ -824,6 +831,8 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
 {
     static const int pfd = env_int("NVX_PREFETCH", 1) == 2 ? 2 : 1;
     static const int nt = env_int("NVX_NT", 1) != 0;
+    static const int early = env_int("NVX_EARLY_RELOAD", 0) != 0;   // measured slower (DESIGN.md tuning log); off
+    nvx_cascade_args args = *a; args.early_reload = early; a = &args;
     // queue counter, status word and per-stream completion counts start at zero every launch
     hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_streams) * sizeof(int), s);
     if (e != hipSuccess) return e;

@@ -50,6 +50,23 @@ __global__ __launch_bounds__(64) void read_streams(const u32x4 *p, size_t pitch1
     if (acc == 0x12345678u) { *sink = acc; pad[threadIdx.x] = 1; *sink += pad[(threadIdx.x + 1) & 63]; }
 }
 
+// burst variant: NB x 8 KiB contiguous requested back to back, then consumed, then the next burst
+template <int LDSB, int NB>
+__global__ __launch_bounds__(64) void read_streams_burst(const u32x4 *p, size_t pitch16, int passes, unsigned *sink)
+{
+    __shared__ char pad[LDSB];
+    const u32x4 *src = p + (size_t)blockIdx.x * pitch16 + threadIdx.x;
+    unsigned acc = 0;
+    u32x4 buf[NB * 8];
+    for (int q = 0; q + NB <= passes; q += NB) {
+#pragma unroll
+        for (int j = 0; j < NB * 8; j++) buf[j] = __builtin_nontemporal_load(src + (size_t)q * 512 + 64 * j);
+#pragma unroll
+        for (int j = 0; j < NB * 8; j++) acc += buf[j].x ^ buf[j].w;
+    }
+    if (acc == 0x12345678u) { *sink = acc; pad[threadIdx.x] = 1; *sink += pad[(threadIdx.x + 1) & 63]; }
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -78,6 +95,9 @@ int main(int argc, char **argv)
     }
 #define B(LDSB, DEPTH) { float ms = time_ms([&] { hipLaunchKernelGGL((read_streams<LDSB, DEPTH>), dim3(streams), dim3(64), 0, 0, (const u32x4 *)d, per / 16, passes, sink); }, 3); \
         printf("B per-stream lds %6d depth %d: %.2f ms  %.0f GB/s\n", LDSB, DEPTH, ms, bytes / ms / 1e6); }
+#define BB(LDSB, NB) { float ms = time_ms([&] { hipLaunchKernelGGL((read_streams_burst<LDSB, NB>), dim3(streams), dim3(64), 0, 0, (const u32x4 *)d, per / 16, passes, sink); }, 3); \
+        printf("C burst %d x 8 KiB lds %6d: %.2f ms  %.0f GB/s\n", NB, LDSB, ms, bytes / ms / 1e6); }
+    BB(14480, 1) BB(14480, 2) BB(14480, 4) BB(20000, 2) BB(20000, 4) BB(40000, 2) BB(40000, 4) BB(80000, 4)
     B(64, 1) B(64, 2) B(4096, 1) B(4096, 2) B(9216, 1) B(9216, 2) B(14480, 1) B(14480, 2) B(20000, 1) B(20000, 2) B(40000, 1) B(40000, 2)
     return 0;
 }
