@@ -1,15 +1,15 @@
-/* Drop-in link test.  A stand-in for the reference's receiver main program that
- * keeps exactly the shape receiver/capt_sched.c has around the hot path:
- *   - the three extern declarations (capt_sched.c:17-19),
- *   - init_dsp() -> init_fir_filter1(), then init_fir2_wrapper() (:552-555, :612),
- *   - an interleaved int16 ring filled by a producer shaped like StreamACallback
- *     (:105-148, planar xi/xq -> I,Q,I,Q... after in_idx, index = last written),
- *   - the consumer loop (:484-528): spans [from..to] with wrap, and for each pair
- *     sample_in_1((double)buf[i], (double)buf[i+1]),
- *   - its own add_message() (as message_store.o provides, message_store.c:59-97).
- * It links against libnavtex_amd.so INSTEAD of fir1cpp/fir2cpp/fir3cpp/decoder/
- * nav_b_sm/nav_sched objects.  Input: interleaved int16 IQ file at 252 kS/s.
- * Output: one line per message on stdout: freq|bbbb|message with \n escaped.   */
+/* Drop-in link test: a stand-in for the receiver's main program.
+ *
+ * What it keeps from the reference's capture layer (receiver/capt_sched.c) is the
+ * CONTRACT around the hot path, not the code:
+ *   - the DSP is reached only through init_fir_filter1(), init_fir2_wrapper() and
+ *     sample_in_1(I, Q) with each int16 widened to double (capt_sched.c:17-19, :511, :554, :612);
+ *   - samples arrive as planar xi[] / xq[] callbacks of varying length and are kept
+ *     interleaved in a ring whose cursor names the LAST WRITTEN slot (capt_sched.c:105-148, :443-446);
+ *   - a consumer drains the ring in contiguous spans, splitting at the wrap (capt_sched.c:484-528);
+ *   - messages leave through the program's own add_message() (message_store.c:59-97).
+ * It links against libnavtex_amd.so in place of the reference's DSP objects.
+ * Input: interleaved int16 IQ at 252 kS/s.  Output: "freq|bbbb|text" per message, '\n' escaped. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,72 +17,73 @@
 void init_fir_filter1();
 void sample_in_1(double sample_I, double sample_Q);
 void init_fir2_wrapper();
-int nvx_shim_flush(void);          /* only so the test can terminate a finite file */
-
-static short *sample_buffer;
-static unsigned int s_buffer_size;
-static int in_idx, out_idx;
+int nvx_shim_flush(void);          /* only so that a finite file can be finished */
 
 int add_message(char *bbbb, char *message, int freq)
 {
     printf("%d|%s|", freq, bbbb);
-    for (char *p = message; *p; p++) { if (*p == '\n') fputs("\\n", stdout); else fputc(*p, stdout); }
+    for (const char *c = message; *c; ++c)
+        if (*c == '\n') fputs("\\n", stdout); else fputc(*c, stdout);
     fputc('\n', stdout);
     return 0;
 }
 
-static void StreamACallback(short *xi, short *xq, void *params, unsigned int numSamples, unsigned int reset, void *cbContext)
+typedef struct {
+    short *slot;                   /* I,Q,I,Q,... */
+    unsigned n_slots;              /* even */
+    unsigned written;              /* index of the newest valid slot */
+    unsigned consumed;             /* index of the newest slot already handed to the DSP */
+} iq_ring;
+
+static void ring_put(iq_ring *r, const short *xi, const short *xq, unsigned count)
 {
-    (void)params; (void)reset; (void)cbContext;
-    unsigned int next_idx = (unsigned int)in_idx + 1;
-    next_idx %= s_buffer_size;
-    for (unsigned int i = 0; i < numSamples; i++) {
-        sample_buffer[next_idx] = xi[i]; next_idx++; next_idx %= s_buffer_size;
-        sample_buffer[next_idx] = xq[i]; next_idx++; next_idx %= s_buffer_size;
+    unsigned w = r->written;
+    for (unsigned k = 0; k < count; ++k) {
+        w = (w + 1) % r->n_slots; r->slot[w] = xi[k];
+        w = (w + 1) % r->n_slots; r->slot[w] = xq[k];
     }
-    in_idx = (next_idx == 0) ? (int)s_buffer_size - 1 : (int)next_idx - 1;
+    r->written = w;
 }
 
-static void consume(void)
+static void ring_drain(iq_ring *r)
 {
-    int c_in_idx = in_idx;
-    while (out_idx != c_in_idx) {
-        int from = out_idx + 1; from %= (int)s_buffer_size;
-        int to = c_in_idx;
-        if (from > to) to = (int)s_buffer_size - 1;
-        int num_samples = to - from + 1, index = from;
-        for (int i = 0; i < num_samples; i += 2) {
-            sample_in_1((double)sample_buffer[index], (double)sample_buffer[index + 1]);
-            index += 2;
-        }
-        out_idx = to;
+    const unsigned target = r->written;
+    while (r->consumed != target) {
+        unsigned first = (r->consumed + 1) % r->n_slots;
+        unsigned last = (first <= target) ? target : r->n_slots - 1;     /* stop at the wrap, come round again */
+        for (unsigned s = first; s < last; s += 2)
+            sample_in_1((double)r->slot[s], (double)r->slot[s + 1]);
+        r->consumed = last;
     }
 }
 
 int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
-    FILE *f = fopen(argv[1], "rb");
-    if (!f) return 2;
-    init_fir_filter1();                /* init_dsp() */
+    FILE *in = fopen(argv[1], "rb");
+    if (!in) return 2;
+
+    init_fir_filter1();
     init_fir2_wrapper();
-    s_buffer_size = 252000 * 2 * 2;    /* 2 s ring (the reference keeps 8 s) */
-    sample_buffer = malloc(s_buffer_size * sizeof(short));
-    in_idx = 1; out_idx = 1;
-    enum { CHUNK = 1008 };             /* the vendor library delivers ~1 k-sample callbacks */
-    short iq[2 * CHUNK], xi[CHUNK], xq[CHUNK];
-    size_t n;
-    unsigned jitter = 12345;
+
+    iq_ring ring;
+    ring.n_slots = 252000u * 2u * 2u;                 /* two seconds (the reference keeps eight) */
+    ring.slot = malloc(ring.n_slots * sizeof(short));
+    ring.written = ring.consumed = 1;                 /* odd start: I lands on even slots, as in the reference */
+
+    enum { MAX_CB = 1008 };                           /* callbacks of about a thousand samples, length jittered */
+    short pairs[2 * MAX_CB], xi[MAX_CB], xq[MAX_CB];
+    unsigned lcg = 12345;
     for (;;) {
-        jitter = jitter * 1103515245u + 12345u;
-        size_t want = 1 + (jitter >> 16) % CHUNK;           /* jittered numSamples */
-        n = fread(iq, 4, want, f);
-        if (!n) break;
-        for (size_t i = 0; i < n; i++) { xi[i] = iq[2 * i]; xq[i] = iq[2 * i + 1]; }
-        StreamACallback(xi, xq, NULL, (unsigned int)n, 0, NULL);
-        consume();
+        lcg = lcg * 1103515245u + 12345u;
+        size_t want = 1 + (lcg >> 16) % MAX_CB;
+        size_t got = fread(pairs, 2 * sizeof(short), want, in);
+        if (!got) break;
+        for (size_t k = 0; k < got; ++k) { xi[k] = pairs[2 * k]; xq[k] = pairs[2 * k + 1]; }
+        ring_put(&ring, xi, xq, (unsigned)got);
+        ring_drain(&ring);
     }
-    fclose(f);
-    nvx_shim_flush();
-    return 0;
+    fclose(in);
+    free(ring.slot);
+    return nvx_shim_flush() == 0 ? 0 : 1;
 }

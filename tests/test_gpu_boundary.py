@@ -75,7 +75,7 @@ def test_stream_callback_shape(nv):
         assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
 
 
-def test_unmodified_capture_loop_links_and_decodes(nv, tmp_path):
+def test_capture_loop_program_links_and_decodes(nv, tmp_path):
     """The reference-shaped main program (tests/harness/capt_loop.c: capt_sched.c's ring,
     callback and consumer loop, its own add_message) linked against libnavtex_amd.so."""
     rec = GOLD["iq"]["two_carrier"]
