@@ -37,8 +37,8 @@ BYTES_PER_SAMPLE = 4           # int16 I + int16 Q, each read from HBM exactly o
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=4096, help="IQ streams per GPU")
     ap.add_argument("--frames", type=int, default=12, help="frames (0.32 s each) resident per stream")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
@@ -217,7 +217,9 @@ def main():
         spec = importlib.util.spec_from_file_location("nvx_build", ROOT / "navtex_amd" / "build.py")
         mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
         if rank == 0:
-            mod.build_lib()
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
+                mod.build_lib()
         if dist is not None:
             dist.barrier()
     import navtex_amd as nv

@@ -41,8 +41,8 @@ def _hipcc() -> str:
 
 
 def _run(cmd):
-    print(" ".join(str(c) for c in cmd), flush=True)
-    subprocess.run([str(c) for c in cmd], check=True)
+    print(" ".join(str(c) for c in cmd), file=sys.stderr, flush=True)
+    subprocess.run([str(c) for c in cmd], check=True, stdout=sys.stderr)
 
 
 def _stale(out: Path, deps) -> bool:
