@@ -215,3 +215,36 @@ def test_full_size_properties_config3(nv, oracle):
             ref.push_raw(iq)
             assert runs[0][s] == ref.bits(0), f"stream {s}"
     buf.free()
+
+
+@pytest.mark.parametrize("raw", [False, True], ids=["252k", "raw2016k"])
+def test_queue_handoff_stress(nv, oracle, raw):
+    """Few streams x many frames in ONE launch: every (stream, frame) unit gets its own workgroup,
+    so each stream is a 48-deep chain of agent-scope release/acquire hand-offs with all consumers
+    spinning at once.  The complete 900 S/s output of every chain must be bit-exact."""
+    rate = nv.RATE_RAW if raw else nv.RATE_IN
+    frame = nv.FRAME_RAW if raw else nv.FRAME_IN
+    n_streams, n_frames = (3, 24) if raw else (5, 48)
+    masks = [3, 1, 2, 3, 1][:n_streams]
+    iqs = []
+    for s in range(n_streams):
+        carriers = [dict(freq_hz=f, bits=nv.sitor_encode(signals.stream_text(900 + s), 10), bit_offset=(131 * (s + 1)) % (rate // 100),
+                         phase0=s * 1234567, amplitude=5000) for f in (14000, -14000)]
+        iqs.append(nv.synth_host(nv.make_stream(carriers, seed=50 + s, noise_amp=2000), rate, n_frames * frame))
+    pitch = n_frames * frame
+    buf = nv.DeviceBuffer(n_streams * pitch * 4)
+    for s in range(n_streams):
+        buf.upload(iqs[s], offset=s * pitch * 4)
+    with nv.Pipeline(n_streams=n_streams, raw_rate=raw, chain_masks=masks, max_frames=n_frames, char_layer=False) as p:
+        for rep in range(3):                               # repeat: L1-warm consumers on the later rounds
+            p.reset()
+            p.process_resident(buf, pitch, 0, n_frames)
+            p.fetch()
+            for s in range(n_streams):
+                ref = oracle.Pipe(chain_mask=masks[s], charlayer=False, tap_y3=n_frames * nv.FRAME_Y3)
+                (ref.push_raw if raw else ref.push)(iqs[s])
+                for c in range(2):
+                    if (masks[s] >> c) & 1:
+                        assert np.array_equal(_u64(p.debug_y3(s, c)), _u64(ref.y3(c))), f"rep {rep} stream {s} chain {c}"
+                        assert p.bits(s, c) == ref.bits(c)
+    buf.free()
