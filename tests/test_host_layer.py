@@ -115,3 +115,19 @@ def test_empty_inputs(nv):
     st = nv.make_stream([], seed=3, noise_amp=0)
     assert np.array_equal(nv.synth_host(st, nv.RATE_IN, 100), np.zeros((100, 2), dtype=np.int16))
     assert nv.synth_host(st, nv.RATE_IN, 0).shape == (0, 2)
+
+
+def test_config0_wav_file_through_the_cpu_reference_path(nv, oracle, tmp_path):
+    """BASELINE configs[0]: a single 518 kHz channel from a WAV file on the CPU path (plumbing, no GPU):
+    nvx_wav writer -> file -> nvx_wav reader -> the oracle pipeline -> the reference's messages."""
+    rec = GOLD["iq"]["two_carrier"]
+    iq = cases.make_iq(nv, rec["spec"])
+    path = str(tmp_path / "capture_518.wav")
+    nv.wav_write(path, iq, nv.RATE_IN)
+    back, rate = nv.wav_read(path)
+    assert rate == 252000 and back.shape == iq.shape and back.shape[0] >= 20 * 252000
+    p = oracle.Pipe(chain_mask=3)
+    for k in range(0, back.shape[0], 65536):               # the frame-count-sized reads a wav_read loop would make
+        p.push(back[k:k + 65536])
+    assert p.bits(0) == rec["bits518"] and [list(m) for m in p.messages] == rec["messages"]
+    assert (518, "EA01", "ZCZC EA01\nTEST MESSAGE 123 OK\nNNNN\n") in p.messages
