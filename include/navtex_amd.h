@@ -143,6 +143,7 @@ typedef struct nvx_config {
                               /* run through the 252 kS/s path.  Decoded stream index = 8*w + k   */
                               /* (k = sub-band, centre k*252 kHz), so chain_masks / labels have   */
                               /* 8*n_streams entries.                                             */
+    int      bit_history;     /* decoded bits kept per chain for nvx_poll_bits (0 = NVX_BIT_HISTORY) */
 } nvx_config;
 
 /* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the
@@ -162,7 +163,12 @@ NVX_API int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq_interleaved
 NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n);
 /* wait for all launched work, deliver bits/messages                          */
 NVX_API int nvx_flush(nvx_handle *h);
-/* copy out and consume decoded bits ('B'/'Y') of one chain; returns count    */
+/* copy out and consume decoded bits ('B'/'Y') of one chain; returns count.
+ * The receiver runs unattended for weeks (receiver/main.c), so the library keeps
+ * only the most recent cfg.bit_history bits per chain (up to twice that between
+ * trims): a reader further behind resumes at the oldest bit still held.  The
+ * character layer sees every bit regardless.                                 */
+#define NVX_BIT_HISTORY 65536
 NVX_API size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, size_t cap);
 
 /* ---- device-resident path (roofline runs; IQ already in HBM) --------------
@@ -308,6 +314,31 @@ NVX_API int  nvx_channelise_time_stats(double *sum_ms, uint64_t *launches, int r
 NVX_API int nvx_channelise_resident(int device, const void *d_raw, size_t pitch_raw, size_t first_sample,
                                     int n_wide, size_t n_out, const void *d_hist_in, void *d_hist_out,
                                     void *d_sub, size_t pitch_sub, size_t sub_first, void *hip_stream);
+
+/* ==========================================================================
+ * H. SQLite message sink: writes decoded messages into the
+ *    database the reference's web server reads, with the semantics of the
+ *    reference's add_message (receiver/message_store.c:59-97: a repeat of the
+ *    same bbbb replaces the earlier row; timestamp = UTC "%Y-%m-%d %H:%M";
+ *    age = 'NEW') and its schema (receiver/generate_db.sql:3-8).  libsqlite3 is
+ *    bound at run time; NVX_ERR_IO if it is not installed.
+ *    When the library's own weak add_message is the sink (nothing else linked
+ *    defines it) and NAVTEX_AMD_DB names a database file, messages go there.
+ * ========================================================================== */
+typedef struct nvx_store nvx_store;
+/* create_schema != 0: create the messages/config tables if they are missing  */
+NVX_API int  nvx_store_open(const char *path, int create_schema, nvx_store **out);
+NVX_API void nvx_store_close(nvx_store *s);
+/* same arguments and return values as add_message: 0, -1 (open failed), -2 (insert failed) */
+NVX_API int  nvx_store_add_message(nvx_store *s, const char *bbbb, const char *message, int freq);
+/* an nvx_message_fn: set cfg.on_message = nvx_store_on_message, cfg.user = the store */
+NVX_API void nvx_store_on_message(void *user, int stream, const char *bbbb, const char *message, int freq);
+/* purge_old_messages (receiver/message_store.c:220-262): delete rows older than
+ * max_age_seconds (<= 0: the reference's 72 h); returns the number deleted or < 0 */
+NVX_API int  nvx_store_purge(nvx_store *s, long max_age_seconds);
+NVX_API void nvx_store_stats(nvx_store *s, uint64_t *added, uint64_t *failed);
+/* test hook: a fixed clock (unix seconds) for timestamps and purge; 0 = wall clock */
+NVX_API void nvx_store_set_time(nvx_store *s, int64_t unix_seconds);
 
 #ifdef __cplusplus
 }

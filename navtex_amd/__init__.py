@@ -17,7 +17,7 @@ from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRA
                       NvxError, lib)
 
 __all__ = ["Pipeline", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
-           "DeviceBuffer", "channelise", "channelise_time_stats", "wav_write", "wav_read", "NvxError", "lib",
+           "DeviceBuffer", "channelise", "channelise_time_stats", "Store", "wav_write", "wav_read", "NvxError", "lib",
            "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
 
 
@@ -146,13 +146,14 @@ class Pipeline:
     def __init__(self, n_streams: int = 1, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
                  chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None,
                  max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0,
-                 wideband: bool = False):
+                 wideband: bool = False, bit_history: int = 0, store: "Optional[Store]" = None):
         self.messages: List[Tuple[int, int, str, str]] = []          # (stream, freq, bbbb, text)
         cfg = N.Config()
         lib.nvx_config_default(C.byref(cfg))
         cfg.device, cfg.n_streams, cfg.raw_rate = device, n_streams, int(raw_rate)
         cfg.chain_mask, cfg.max_frames, cfg.char_layer, cfg.push_mode = chain_mask, max_frames, int(char_layer), int(push_mode)
         cfg.wideband = int(wideband)
+        cfg.bit_history = int(bit_history)
         if chain_masks is not None:
             chain_masks = list(chain_masks)
             self._masks = (C.c_uint8 * len(chain_masks))(*chain_masks)
@@ -163,6 +164,10 @@ class Pipeline:
             cfg.labels = self._labels
         self._cb = N.MESSAGE_FN(lambda u, s, b, m, f: self.messages.append((s, f, b.decode("latin1"), m.decode("latin1"))))
         cfg.on_message = self._cb
+        if store is not None:                        # messages go straight from the C character layer into SQLite
+            cfg.on_message = C.cast(lib.nvx_store_on_message, N.MESSAGE_FN)
+            cfg.user = store._s
+            self._store = store
         self.n_streams, self.raw_rate, self.max_frames, self.device = n_streams, bool(raw_rate), max_frames, device
         self.wideband = bool(wideband)
         self.frame = FRAME_RAW if (raw_rate or wideband) else FRAME_IN
@@ -262,6 +267,40 @@ class Pipeline:
 
 
 # ----------------------------------------------------------------------- WAV
+class Store:
+    """nvx_store wrapper: the SQLite sink the reference's web server reads (message_store.c:59-97)."""
+
+    def __init__(self, path: str, create_schema: bool = True):
+        s = C.c_void_p()
+        N.check(lib.nvx_store_open(str(path).encode(), int(create_schema), C.byref(s)), "nvx_store_open")
+        self._s = s
+
+    def add_message(self, bbbb: str, message: str, freq: int) -> int:
+        return lib.nvx_store_add_message(self._s, bbbb.encode("latin1"), message.encode("latin1"), freq)
+
+    def purge(self, max_age_seconds: int = 0) -> int:
+        return N.check(lib.nvx_store_purge(self._s, max_age_seconds), "nvx_store_purge")
+
+    def set_time(self, unix_seconds: int) -> None:
+        lib.nvx_store_set_time(self._s, unix_seconds)
+
+    def stats(self) -> Tuple[int, int]:
+        a, f = C.c_uint64(), C.c_uint64()
+        lib.nvx_store_stats(self._s, C.byref(a), C.byref(f))
+        return a.value, f.value
+
+    def close(self) -> None:
+        if self._s:
+            lib.nvx_store_close(self._s)
+            self._s = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def wav_write(path: str, iq: np.ndarray, rate: int = RATE_IN) -> None:
     """2-channel 16-bit PCM, as receiver/capt_sched.c:87-96 configures its capture file."""
     iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)

@@ -30,6 +30,7 @@ class Config(C.Structure):
         ("chain_masks", C.POINTER(C.c_uint8)), ("labels", C.POINTER(C.c_int)), ("max_frames", C.c_int),
         ("char_layer", C.c_int), ("on_message", MESSAGE_FN), ("user", C.c_void_p), ("push_mode", C.c_int),
         ("wideband", C.c_int),
+        ("bit_history", C.c_int),
     ]
 
 
@@ -87,6 +88,11 @@ def _load() -> C.CDLL:
         "nvx_channelise_resident": (i, [i, vp, sz, sz, i, sz, vp, vp, vp, sz, sz, vp]),
         "nvx_handle_stream": (vp, [vp]), "nvx_channelise_timing": (None, [i]),
         "nvx_channelise_time_stats": (i, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]),
+        "nvx_store_open": (i, [C.c_char_p, i, C.POINTER(vp)]), "nvx_store_close": (None, [vp]),
+        "nvx_store_add_message": (i, [vp, C.c_char_p, C.c_char_p, i]),
+        "nvx_store_on_message": (None, [vp, i, C.c_char_p, C.c_char_p, i]),
+        "nvx_store_purge": (i, [vp, C.c_long]), "nvx_store_set_time": (None, [vp, C.c_int64]),
+        "nvx_store_stats": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -23,7 +23,7 @@ OBJ = PKG / "_obj"
 LIB = PKG / "libnavtex_amd.so"
 ARCH = "gfx950"
 
-C_SOURCES = ["nvx_sitor.c", "nvx_wav.c", "nvx_synth_host.c"]
+C_SOURCES = ["nvx_sitor.c", "nvx_wav.c", "nvx_synth_host.c", "nvx_store.c"]
 HIP_SOURCES = ["nvx_kernels.hip"]
 CXX_SOURCES = ["nvx_api.cpp"]
 
@@ -73,7 +73,7 @@ def build_lib(force: bool = False) -> Path:
             _run([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-std=c++17", "-Wall", "-Wno-unused-value", "-Wno-unused-result", *COMMON, "-c", CSRC / src, "-o", o])
         objs.append(o)
     if force or _stale(LIB, objs):
-        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lpthread"])
+        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lpthread", "-ldl"])
     return LIB
 
 

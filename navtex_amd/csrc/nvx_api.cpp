@@ -66,8 +66,9 @@ struct Message { std::string bbbb, text; int freq; };
 struct Slot {                          // one (stream, chain)
     bool active = false;
     int label = 0;
-    std::string bits;                  // everything decoded since create/reset
-    size_t polled = 0;                 // nvx_poll_bits cursor
+    std::string bits;                  // the most recent decoded bits (at most 2*NVX_BIT_HISTORY of them)
+    size_t base = 0;                   // absolute index (since create/reset) of bits[0]
+    size_t polled = 0;                 // nvx_poll_bits cursor, absolute
     nvx_sitor *sitor = nullptr;
     std::vector<Message> outbox;       // messages completed during a (possibly threaded) collect
 };
@@ -85,6 +86,7 @@ struct nvx_handle {
     nvx_config cfg{};
     int n_streams = 0, n_slots = 0, nch = 1;   // n_streams: 252 kS/s-path streams (8 per input in wideband mode)
     int n_in = 0;                      // input streams the caller addresses (= n_streams unless wideband)
+    size_t bit_history = NVX_BIT_HISTORY;
     bool cascade_raw = false;          // the cascade kernel's RAW switch (never set in wideband mode)
     size_t frame_in = 0;               // complex input samples per frame at the input rate
     // wideband mode: channeliser on stream3 into sub[b], overlapping the cascade of the previous launch
@@ -140,8 +142,20 @@ static void sitor_sink(void *user, const char *bbbb, const char *message, int fr
 
 static void deliver_outbox(nvx_handle *h, int stream, Slot &s);
 
+// Default sink when nothing else in the program defines add_message (the reference's
+// message_store.c does): the database named by NAVTEX_AMD_DB, else stdout.
 extern "C" __attribute__((weak, visibility("default"))) int add_message(char *bbbb, char *message, int freq)
 {
+    static std::once_flag once;
+    static nvx_store *store = nullptr;
+    std::call_once(once, [] {
+        const char *path = getenv("NAVTEX_AMD_DB");
+        if (path && *path && nvx_store_open(path, 1, &store) != NVX_OK) {
+            fprintf(stderr, "navtex_amd: NAVTEX_AMD_DB=%s: %s\n", path, nvx_last_error());
+            abort();                             // a configured sink that cannot be opened must not lose messages quietly
+        }
+    });
+    if (store) return nvx_store_add_message(store, bbbb, message, freq);
     printf("[navtex_amd] message freq=%d bbbb=%s\n%s", freq, bbbb, message);
     fflush(stdout);
     return 0;
@@ -217,6 +231,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     h->cascade_raw = cfg->raw_rate && !cfg->wideband;
     h->frame_in = (cfg->raw_rate || cfg->wideband) ? (size_t)NVX_FRAME_RAW : (size_t)NVX_FRAME_IN;
     h->y3_cap = cfg->max_frames * NVX_FRAME_Y3;
+    if (cfg->bit_history < 0) { nvx_set_error("nvx_create: negative bit_history"); delete h; return NVX_ERR_ARG; }
+    if (cfg->bit_history > 0) h->bit_history = (size_t)cfg->bit_history;
     // a bit needs >= 8 samples (the offset slews by at most 1 per bit); packed 8 bits per byte, whole words
     h->bits_cap = (((h->y3_cap / 8 + 8) + 31) / 32) * 4;
     h->masks.resize(h->n_streams);
@@ -225,7 +241,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     for (int s = 0; s < h->n_streams; s++) {
         uint8_t m = cfg->chain_masks ? cfg->chain_masks[s] : (uint8_t)cfg->chain_mask;
         m &= 3;
-        if (!m) { nvx_set_error("nvx_create: stream %d has an empty chain mask", s); delete h; return NVX_ERR_ARG; }
+        if (!m) { nvx_set_error("nvx_create: stream %d has an empty chain mask", s); free_handle(h); return NVX_ERR_ARG; }
         h->masks[s] = m;
         if (m == 3) any_two = true;
         for (int c = 0; c < 2; c++) {
@@ -328,7 +344,7 @@ extern "C" int nvx_reset(nvx_handle *h)
     }
     HIP_TRY(hipMemcpyAsync(h->d_di, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (auto &s : h->slots) { s.bits.clear(); s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
+    for (auto &s : h->slots) { s.bits.clear(); s.base = 0; s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
     if (!h->fill.empty()) std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
     return NVX_OK;
 }
@@ -431,7 +447,7 @@ static int collect_locked(nvx_handle *h)
                 HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[2], r.ev[3]));
                 h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
             }
-            int bad_slot = -1;
+            std::atomic<int> bad_slot{ -1 };
             auto work = [&](int lo, int hi) {
                 for (int i = lo; i < hi; i++) {
                     Slot &s = h->slots[i];
@@ -443,6 +459,11 @@ static int collect_locked(nvx_handle *h)
                     s.bits.resize(at + (size_t)n);
                     for (int k = 0; k < n; k++) s.bits[at + k] = ((pw[k >> 5] >> (k & 31)) & 1u) ? 'B' : 'Y';
                     if (s.sitor) nvx_sitor_receive_bits(s.sitor, s.bits.data() + at, (size_t)n);
+                    if (s.bits.size() > 2 * h->bit_history) {                // a receiver runs for weeks: bound the poll history
+                        const size_t drop = s.bits.size() - h->bit_history;
+                        s.bits.erase(0, drop);
+                        s.base += drop;
+                    }
                 }
             };
             static const int host_threads = [] {
@@ -459,7 +480,7 @@ static int collect_locked(nvx_handle *h)
             } else {
                 work(0, h->n_slots);
             }
-            if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot); return NVX_ERR_STATE; }
+            if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot.load()); return NVX_ERR_STATE; }
             for (int i = 0; i < h->n_slots; i++) if (!h->slots[i].outbox.empty()) deliver_outbox(h, i / 2, h->slots[i]);
             r.pending = false;
         }
@@ -503,7 +524,8 @@ extern "C" size_t nvx_bit_count(nvx_handle *h, int stream, int chain)
 {
     if (!h || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
     std::lock_guard<std::mutex> lk(h->mu);
-    return h->slots[2 * stream + chain].bits.size();
+    const Slot &s = h->slots[2 * stream + chain];
+    return s.base + s.bits.size();
 }
 
 extern "C" size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, size_t cap)
@@ -511,8 +533,9 @@ extern "C" size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out,
     if (!h || !out || stream < 0 || stream >= h->n_streams || chain < 0 || chain > 1) return 0;
     std::lock_guard<std::mutex> lk(h->mu);
     Slot &s = h->slots[2 * stream + chain];
-    size_t n = std::min(cap, s.bits.size() - s.polled);
-    memcpy(out, s.bits.data() + s.polled, n);
+    if (s.polled < s.base) s.polled = s.base;                 // the reader fell more than the history behind
+    size_t n = std::min(cap, s.base + s.bits.size() - s.polled);
+    memcpy(out, s.bits.data() + (s.polled - s.base), n);
     s.polled += n;
     return n;
 }

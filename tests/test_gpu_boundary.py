@@ -291,3 +291,52 @@ def test_empty_and_tiny_pushes(nv):
         p.push(0, np.zeros((1, 2), dtype=np.int16))      # less than a frame: staged, nothing launched
         p.flush()
         assert p.bits(0, 0) == ""
+
+
+def test_bit_history_is_bounded_and_counts_stay_absolute(nv):
+    """A receiver runs for weeks: the poll history per chain is capped (cfg.bit_history),
+    the total count keeps running, a slow reader resumes at the oldest bit still held and
+    what it reads is the tail of the full bit string; the character layer misses nothing."""
+    import signals
+    frames = 16                                      # 512 bit periods, the first 66 go to priming
+    s = signals.stream_params(nv, 4242, nv.RATE_RAW)[0]
+    pitch = frames * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(pitch * 4)
+    nv.synth_device([s], nv.RATE_RAW, pitch, buf, pitch)
+    hist = 64
+    with nv.Pipeline(n_streams=1, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=1, char_layer=True) as full, \
+         nv.Pipeline(n_streams=1, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=1, char_layer=True,
+                     bit_history=hist) as capped:
+        early = ""
+        for f in range(frames):
+            for p in (full, capped):
+                p.process_resident(buf, pitch, f, 1)
+                p.fetch()
+            if f == 3:
+                early = capped.bits(0, 0)            # a reader that keeps up loses nothing
+        want = full.bits(0, 0)
+        assert early == want[: len(early)] and len(early) > 0
+        assert capped.bit_count(0, 0) == full.bit_count(0, 0) == len(want) > 4 * hist
+        got = capped.bits(0, 0)                      # early bits + what is still held after the gap
+        tail = got[len(early):]
+        assert hist <= len(tail) <= 2 * hist + 32 and want.endswith(tail)
+        assert capped.messages == full.messages
+    buf.free()
+
+
+def test_messages_land_in_the_sqlite_database(nv, tmp_path):
+    """IQ in, rows out: the C character layer writes straight into the database the
+    reference's web server reads (nvx_store_on_message as the handle's sink)."""
+    import sqlite3
+    rec = GOLD["iq"]["two_carrier"]
+    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    db = str(tmp_path / "Navtex.db")
+    with nv.Store(db) as st, nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True, store=st) as p:
+        p.push(0, iq)
+        p.flush()
+        assert st.stats() == (len(rec["messages"]), 0) and p.messages == []
+    con = sqlite3.connect(db)
+    got = con.execute("select freq,bbbb,message,age from messages order by id").fetchall()
+    con.close()
+    assert sorted([f, b, m] for (f, b, m, _a) in got) == sorted(rec["messages"])
+    assert all(a == "NEW" for (*_x, a) in got) and len(got) >= 2
