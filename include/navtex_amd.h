@@ -114,6 +114,10 @@ NVX_API void nvx_capture_callback(short *xi, short *xq, void *params, unsigned i
 NVX_API int  nvx_capture_stop(nvx_capture *c);
 /* complex samples offered by the producer / dropped on overrun / handed to the GPU pipeline */
 NVX_API void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed);
+/* debug recording (the reference's debug_mode, capt_sched.c:87-101 PrepWav/EndWav and :516):
+ * every span the consumer hands to the pipeline is also appended to a 2-channel 16-bit WAV
+ * at the handle's input rate.  filename NULL stops and closes; nvx_capture_stop closes too. */
+NVX_API int  nvx_capture_record(nvx_capture *c, const char *filename);
 /* test hook: pause (1) / resume (0) the consumer, to provoke an overrun deterministically */
 NVX_API void nvx_capture_pause(nvx_capture *c, int paused);
 

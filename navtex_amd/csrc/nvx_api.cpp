@@ -936,6 +936,7 @@ struct nvx_capture {
     std::mutex cv_mu; std::condition_variable cv;
     std::atomic<bool> stop{ false }, paused{ false };
     std::atomic<int> error{ NVX_OK };
+    std::mutex rec_mu; nvx_wav *rec = nullptr;  // debug recording of what the consumer hands on (capt_sched.c:87-101, 516)
     std::thread worker;
 };
 
@@ -955,6 +956,12 @@ static void capture_consumer(nvx_capture *c)
             size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
             int rc = nvx_push_iq(c->h, c->stream, c->ring.data() + 2 * at, n);
             if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }
+            {
+                std::lock_guard<std::mutex> lk(c->rec_mu);
+                if (c->rec && nvx_wav_write(c->rec, c->ring.data() + 2 * at, n) != n) {     // disk full etc.: stop recording, keep decoding
+                    nvx_wav_close(c->rec); c->rec = nullptr;
+                }
+            }
             t += n;
             c->tail.store(t);
             c->consumed.fetch_add(n);
@@ -998,6 +1005,22 @@ extern "C" void nvx_capture_callback(short *xi, short *xq, void *params, unsigne
     c->cv.notify_one();
 }
 
+extern "C" int nvx_capture_record(nvx_capture *c, const char *filename)
+{
+    if (!c) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->rec_mu);
+    if (c->rec) { nvx_wav_close(c->rec); c->rec = nullptr; }
+    if (!filename) return NVX_OK;
+    nvx_wav *w = nvx_wav_open(filename, NVX_WAV_OPEN_WRITE);
+    if (!w) { nvx_set_error("nvx_capture_record: %s", nvx_wav_err()); return NVX_ERR_IO; }
+    nvx_wav_set_format(w, 1);                                            // PrepWav, capt_sched.c:87-96
+    nvx_wav_set_num_channels(w, 2);
+    nvx_wav_set_sample_rate(w, (c->h->cfg.raw_rate || c->h->cfg.wideband) ? NVX_RATE_RAW : NVX_RATE_IN);
+    nvx_wav_set_sample_size(w, sizeof(short));
+    c->rec = w;
+    return NVX_OK;
+}
+
 extern "C" void nvx_capture_pause(nvx_capture *c, int paused)
 {
     if (!c) return;
@@ -1022,6 +1045,7 @@ extern "C" int nvx_capture_stop(nvx_capture *c)
     if (c->worker.joinable()) c->worker.join();
     int rc = c->error.load();
     if (rc == NVX_OK) rc = nvx_flush(c->h);
+    if (c->rec) nvx_wav_close(c->rec);                                   // EndWav, capt_sched.c:98-101
     delete c;
     return rc;
 }

@@ -32,7 +32,6 @@ typedef struct {
     int *status;               /* = queue + 1                                          */
     int *done;                 /* = queue + 2: frames completed per stream             */
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid      */
-    int early_reload;          /* set by the launcher: re-request each load right after its use */
 } nvx_cascade_args;
 
 typedef struct {

@@ -105,12 +105,44 @@ __device__ __forceinline__ int dpp_swap_pairs(int v)
 
 // stage 0 for one 1-KiB load: lane l holds raw samples 4l..4l+3 of the KiB;
 // lanes (2i, 2i+1) together hold the 8 samples of output i.  Even lanes produce
-// the I sum, odd lanes the Q sum: each lane adds up ITS component of its own
-// four samples (mine) and the PARTNER's component of them (other), then one DPP
-// pair-swap add completes both sums.  The selectors are per-lane registers
-// ((1,0) picks I, (0,1) picks Q), so no v_cndmask is needed.
-__device__ __forceinline__ double stage0_component(u32x4 v, nvx_short2 sel_mine, nvx_short2 sel_other)
+// the I sum, odd lanes the Q sum.  Each lane adds up both components of its own
+// four samples -- two SDWA adds take the sign-extended low (I) or high (Q)
+// halves of two words at once, a third add joins the pairs -- keeps its own
+// component, hands the other one to its partner, and one DPP pair-swap add
+// completes both sums.  11 VALU instructions per load, ~34 issue cycles
+// (tools/valu_probe3.hip: SDWA and v_dot2c both issue in 4 cycles, plain VOP2
+// in 2; the earlier form, eight v_dot2c with per-lane selector registers, took
+// ~44).  -DNVX_STAGE0_DOT2C builds that earlier form for A/B runs.
+#ifndef NVX_STAGE0_DOT2C
+__device__ __forceinline__ int add_low_halves(unsigned a, unsigned b)
 {
+    int r;
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0"
+        : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int add_high_halves(unsigned a, unsigned b)
+{
+    int r;
+    asm("v_add_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1"
+        : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
+{
+    const int sI = add_low_halves(v.x, v.y) + add_low_halves(v.z, v.w);
+    const int sQ = add_high_halves(v.x, v.y) + add_high_halves(v.z, v.w);
+    int mine = (odd ? sQ : sI) + 4;                           // + 4: round half up
+    const int other = odd ? sI : sQ;
+    asm("" : "+v"(mine));                                     // keeps the two VOP2 adds (2 cycles each, the second with the
+    const int tot = mine + dpp_swap_pairs(other);             // DPP operand) from being merged into a v_mov_dpp + 4-cycle v_add3
+    return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
+}
+#else
+__device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
+{
+    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };          // (1,0) picks I, (0,1) picks Q
+    const nvx_short2 sel_mine = odd ? selQ : selI, sel_other = odd ? selI : selQ;
     int mine = 2, other = 2;                  // 2 + 2 = the +4 of round-half-up
     mine  = __builtin_amdgcn_sdot2(as_short2(v.x), sel_mine,  mine,  false);
     other = __builtin_amdgcn_sdot2(as_short2(v.x), sel_other, other, false);
@@ -123,6 +155,7 @@ __device__ __forceinline__ double stage0_component(u32x4 v, nvx_short2 sel_mine,
     const int tot = mine + dpp_swap_pairs(other);
     return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
 }
+#endif
 
 template <bool RAW, bool NT>
 __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 *src)
@@ -155,7 +188,6 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 {
     __shared__ CascadeLds<NCH> lds;
     const int lane = threadIdx.x;
-    const bool EARLY = a.early_reload != 0;          // wave-uniform launch option (A/B switch)
 
     if (lane < NVX_MIX_N) {
         // constant-index selects keep the tables out of scratch
@@ -173,8 +205,6 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
     // phase r = m & 3, index k' = m >> 2 = 8j + (lane>>3), component = lane & 1
     double *xw = (double *)&lds.X[((lane >> 1) & 3) * XS + 9 + (lane >> 3)] + (lane & 1);
     const bool odd = lane & 1;
-    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };
-    const nvx_short2 sel_mine = odd ? selQ : selI, sel_other = odd ? selI : selQ;
     // FIR1 read base of this lane: X[r*XS + 9 + lane - q]
     const double2 *xr = &lds.X[9 + lane];
     // FIR2 / FIR3: lane = 2*output + component
@@ -245,14 +275,8 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
             if (RAW) {
-                // A/B option (off): request each 1-KiB load register again (for pass + PFD) as soon as its own
-                // stage-0 sums are taken.  Keeps 8 KiB in flight almost continuously -- and measured 2-3 % slower
-                const bool more = pass + PFD < NVX_PASSES_PER_FRAME;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    xw[j * 16] = stage0_component(pf[j], sel_mine, sel_other);   // +8 double2 entries per load
-                    if (EARLY && more) pf[j] = NT ? __builtin_nontemporal_load(nxt + 64 * j) : nxt[64 * j];
-                }
+                for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], odd);   // +8 double2 entries per load
             } else {
                 // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
                 const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 }
             }
             // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
-            if (!(RAW && EARLY) && pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
+            if (pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
 
@@ -831,8 +855,6 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
 {
     static const int pfd = env_int("NVX_PREFETCH", 1) == 2 ? 2 : 1;
     static const int nt = env_int("NVX_NT", 1) != 0;
-    static const int early = env_int("NVX_EARLY_RELOAD", 0) != 0;   // measured slower (DESIGN.md tuning log); off
-    nvx_cascade_args args = *a; args.early_reload = early; a = &args;
     // queue counter, status word and per-stream completion counts start at zero every launch
     hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_streams) * sizeof(int), s);
     if (e != hipSuccess) return e;

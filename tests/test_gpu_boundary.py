@@ -340,3 +340,28 @@ def test_messages_land_in_the_sqlite_database(nv, tmp_path):
     con.close()
     assert sorted([f, b, m] for (f, b, m, _a) in got) == sorted(rec["messages"])
     assert all(a == "NEW" for (*_x, a) in got) and len(got) >= 2
+
+
+def test_capture_debug_recording_reproduces_the_input(nv, tmp_path):
+    """The reference's debug_mode (capt_sched.c:87-101, 516): what the consumer hands to the
+    DSP is also written to a 252 kHz 2-channel WAV; replaying that file gives the same bits."""
+    import signals
+    st, _ = signals.stream_params(nv, 77, nv.RATE_IN)
+    n = 6 * nv.FRAME_IN
+    iq = nv.synth_host(st, nv.RATE_IN, n)
+    xi, xq = np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])
+    path = str(tmp_path / "NTcapture.wav")
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True) as p:
+        cap = _capture(nv, p, 8.0)                        # the reference's 8 s ring: no overrun here
+        assert nv.lib.nvx_capture_record(cap, str(tmp_path / "no_dir" / "x.wav").encode()) < 0
+        assert nv.lib.nvx_capture_record(cap, path.encode()) == 0
+        for pos in range(0, n, 2520):
+            m = min(2520, n - pos)
+            nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap)
+        assert nv.lib.nvx_capture_stop(cap) == 0          # drains, flushes, closes the recording
+        live = p.bits(0, 0)
+    got, rate = nv.wav_read(path)
+    assert rate == nv.RATE_IN and np.array_equal(got, iq)
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True) as p:
+        assert p.decode_wav(path) == 6
+        assert p.bits(0, 0) == live and len(live) > 100

@@ -41,7 +41,8 @@ def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
     main = next(v for k, v in kernels.items() if "nvx_fir_cascadeILb1ELi1ELi1ELb1" in k)
     assert len(re.findall(r"global_load_dwordx4 .* nt", main)) >= 16   # 8 per pass, prologue + loop
     assert "scratch_" not in main and "buffer_store" not in main
-    assert main.count("v_dot2c_i32_i16") >= 64                         # stage 0: 8 per load, 8 loads
+    assert main.count("v_add_u32_sdwa") >= 32                          # stage 0: 4 half-word pair adds per load, 8 loads
+    assert main.count("v_add_u32_dpp") >= 8 and "v_add3_u32" not in main.split("v_add_u32_sdwa", 1)[1].split("ds_read_b128", 1)[0]
     assert "s_barrier" not in main                                     # single-wave workgroups: compiler fences only
 
 
