@@ -8,6 +8,17 @@
 
 #define NVX_PASSES_PER_FRAME 315          /* 20160 FIR1 outputs per frame / 64 per pass */
 #define NVX_Y3_PER_FRAME 288
+/* A work unit of the cascade is 1/NVX_UNIT_SPLIT of a frame.  A third of a frame (105 passes =
+ * 6720 FIR1 outputs = 960 FIR2 outputs = 96 FIR3 outputs) still ends with every pending buffer
+ * empty (6720 = 30 * 224 = 60 * 112, 960 = 6 * 160 = 12 * 80); only the mixer index does not
+ * return to 0 (6720 mod 9 = 6).  Thirds would shorten the ragged end of the persistent grid, but
+ * measured no faster than whole frames (20.58 vs 20.39-20.53 ms, DESIGN.md tuning log): 1 is shipped,
+ * -DNVX_UNIT_SPLIT=3 builds the other for A/B runs (parity-tested). */
+#ifndef NVX_UNIT_SPLIT
+#define NVX_UNIT_SPLIT 1
+#endif
+#define NVX_UNIT_PASSES (NVX_PASSES_PER_FRAME / NVX_UNIT_SPLIT)
+#define NVX_UNIT_Y3 (NVX_Y3_PER_FRAME / NVX_UNIT_SPLIT)
 #define NVX_CASCADE_CTRL_INTS 2           /* [0] work-queue counter, [1] status (non-zero = spin timeout) */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
  * outputs and 70 FIR2 outputs, all fp64 pairs                                 */

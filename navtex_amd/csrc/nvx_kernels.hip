@@ -170,18 +170,39 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 }
 
 // Work distribution: a persistent grid (as many single-wave workgroups as fit
-// on the chip) pulls units u = frame * n_streams + stream from an atomic
-// counter.  A unit is one frame (315 passes, 2.5 MiB raw) of one stream; the
-// FIR histories travel from unit (stream, f) to (stream, f+1) through the
-// per-stream state block in HBM, ordered by done[stream] with the agent-scope
-// release / acquire protocol (the two units usually run on different CUs).
-// Units are handed out frame-major, so a unit's predecessor was taken n_streams
+// on the chip) pulls units u = part * n_streams + stream from an atomic
+// counter.  A unit is one frame (315 passes, 2.5 MiB raw) of one stream (or a
+// third of one, NVX_UNIT_SPLIT); the FIR histories travel from unit (stream, p)
+// to (stream, p+1) through the per-stream state block in HBM: the producer
+// writes it with agent-scope atomic stores, drains them (vmcnt 0) and then sets
+// done[stream]; the consumer polls done[stream] and reads the block with
+// agent-scope atomic loads (the two units usually run on different XCDs).
+// Units are handed out part-major, so a unit's predecessor was taken n_streams
 // units earlier by a workgroup that is already running: the wait cannot
 // deadlock whatever the residency, and every spin is bounded anyway.
 // Why: LDS limits residency to 11 waves per CU (2816), so 4096 equal-length
 // per-stream jobs would run as a VALU-saturated first round and a
 // latency-bound tail of 1280; frame-sized units keep every CU full to the end.
 #define NVX_SPIN_LIMIT (1 << 22)
+
+// The state block is the only memory one unit writes and another unit (usually on another XCD,
+// behind another L2) reads within a launch.  Every access to it is an agent-scope relaxed atomic
+// (global_load / global_store ... sc1: coherent at the device level per instruction), so the
+// hand-off needs no whole-cache maintenance: a release / acquire FENCE at agent scope costs an L2
+// write-back (buffer_wbl2 sc1) and an L1 + L2 invalidate (buffer_inv sc1) per unit on gfx950, paid by
+// every wave that shares the XCD.
+__device__ __forceinline__ double2 state_load(const double2 *p)
+{
+    double2 r;
+    r.x = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.y = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+__device__ __forceinline__ void state_store(double2 *p, double2 v)
+{
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <bool RAW, int NCH, int PFD, bool NT>
 __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
@@ -210,7 +231,8 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
     // FIR2 / FIR3: lane = 2*output + component
     const int half = lane >> 1, comp = lane & 1;
     const int lane_mod9 = lane % 9;
-    const int n_units = a.n_streams * a.n_frames;
+    static_assert(NVX_UNIT_SPLIT == 1 || NVX_UNIT_SPLIT == 3, "a unit must end with all pending buffers empty");
+    const int n_units = a.n_streams * a.n_frames * NVX_UNIT_SPLIT;
 
     for (;;) {
         // ------------------------------------------------------ next unit
@@ -218,8 +240,8 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         if (lane == 0) u = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
-        const int frame = u / a.n_streams;
-        const int stream = u - frame * a.n_streams;
+        const int part = u / a.n_streams;              // index of this unit in its stream: frame * NVX_UNIT_SPLIT + third
+        const int stream = u - part * a.n_streams;
 
         const unsigned mask = a.chain_masks[stream];
         // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
@@ -227,29 +249,33 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 
         // the input does not depend on the predecessor: request the first pass(es) now
         const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) +
-                           (size_t)frame * NVX_PASSES_PER_FRAME * pass_stride + lane;
+                           (size_t)part * NVX_UNIT_PASSES * pass_stride + lane;
         u32x4 pfA[NPF], pfB[NPF];
         load_pass<RAW, NT>(pfA, src);
         if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
         const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
 
-        // ------------------------------------------------------ wait for (stream, frame-1)
-        if (frame > 0) {
+        // ------------------------------------------------------ wait for (stream, part-1)
+        if (part > 0) {
             int spins = 0, ok = 0;
             do {
                 int d = 0;
                 if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 d = __builtin_amdgcn_readfirstlane(d);
-                ok = d >= frame;
+                ok = d >= part;
                 if (!ok) __builtin_amdgcn_s_sleep(32);
             } while (!ok && ++spins < NVX_SPIN_LIMIT);
             if (!ok) {                                   // give up loudly rather than hang the GPU
                 if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+#ifdef NVX_HANDOFF_FENCES
             // one agent-scope acquire per unit: the state lines may sit stale in this CU's L1
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            asm volatile("" ::: "memory");               // the state loads below stay below the flag poll
+#endif
         }
 
         // ------------------------------------------------------ state in
@@ -257,20 +283,21 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         NVX_WAVE_LDS_FENCE();
         if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
             int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
-            lds.X[r * XS + e] = st[lane];
+            lds.X[r * XS + e] = state_load(st + lane);
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             const double2 *su = st + 36 + ch * (46 + 70);
-            if (lane < 46) lds.U[c][lane] = su[lane];
-            lds.Y2[c][lane] = su[46 + lane];
-            if (lane < 6) lds.Y2[c][64 + lane] = su[46 + 64 + lane];
+            if (lane < 46) lds.U[c][lane] = state_load(su + lane);
+            lds.Y2[c][lane] = state_load(su + 46 + lane);
+            if (lane < 6) lds.Y2[c][64 + lane] = state_load(su + 46 + 64 + lane);
         }
         NVX_WAVE_LDS_FENCE();
 
-        int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = 0;
-        const size_t y3_row0 = (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)frame * NVX_Y3_PER_FRAME;
+        // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start)
+        int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = ((part % NVX_UNIT_SPLIT) * (NVX_UNIT_PASSES * 64)) % NVX_MIX_N;
+        const size_t y3_row0 = (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_UNIT_Y3;
 
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 }
             }
             // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
-            if (pass + PFD < NVX_PASSES_PER_FRAME) load_pass<RAW, NT>(pf, nxt);
+            if (pass + PFD < NVX_UNIT_PASSES) load_pass<RAW, NT>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
 
@@ -396,33 +423,35 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         };
 
         if (PFD == 2) {
-            for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass += 2) {
+            for (int pass = 0; pass < NVX_UNIT_PASSES; pass += 2) {
                 body(pfA, pass);
-                if (pass + 1 < NVX_PASSES_PER_FRAME) body(pfB, pass + 1);
+                if (pass + 1 < NVX_UNIT_PASSES) body(pfB, pass + 1);
             }
         } else {
-            for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass++) body(pfA, pass);
+            for (int pass = 0; pass < NVX_UNIT_PASSES; pass++) body(pfA, pass);
         }
 
         // ------------------------------------------------------ state out
         NVX_WAVE_LDS_FENCE();
         if (lane < 36) {
             int e = lane >> 2, r = lane & 3;
-            st[lane] = lds.X[r * XS + e];
+            state_store(st + lane, lds.X[r * XS + e]);
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             double2 *su = st + 36 + ch * (46 + 70);
-            if (lane < 46) su[lane] = lds.U[c][lane];
-            su[46 + lane] = lds.Y2[c][lane];
-            if (lane < 6) su[46 + 64 + lane] = lds.Y2[c][64 + lane];
+            if (lane < 46) state_store(su + lane, lds.U[c][lane]);
+            state_store(su + 46 + lane, lds.Y2[c][lane]);
+            if (lane < 6) state_store(su + 46 + 64 + lane, lds.Y2[c][64 + lane]);
         }
-        // publish: stores drained, agent-scope release, then the flag
+        // publish: the state stores (write-through, sc1) have completed at device level once vmcnt is 0; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NVX_HANDOFF_FENCES
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(a.done + stream, frame + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        if (lane == 0) __hip_atomic_store(a.done + stream, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -845,7 +874,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     int per_cu = fit_per_cu;
     if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;
     const int resident = n_cus * per_cu;
-    const long long units = (long long)a->n_streams * a->n_frames;
+    const long long units = (long long)a->n_streams * a->n_frames * NVX_UNIT_SPLIT;
     const unsigned grid = (unsigned)(units < resident ? units : resident);
     hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, *a);
     return hipGetLastError();
