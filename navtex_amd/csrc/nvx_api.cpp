@@ -77,7 +77,7 @@ struct Result {                        // one in-flight launch's bit output
     uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
     uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
     hipEvent_t done = nullptr;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };   // cascade begin/end (stream 1), demod begin/end (stream 2)
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
     bool timed = false;
     bool pending = false;
 };
@@ -98,9 +98,10 @@ struct nvx_handle {
     uint64_t wide_launches = 0;
     int y3_cap = 0, bits_cap = 0;
     hipStream_t stream = nullptr;      // FIR cascade (or the caller's stream) and H2D staging
-    hipStream_t stream2 = nullptr;     // demodulator + D2H of the bits: overlaps the next cascade launch
+    hipStream_t stream2 = nullptr;     // demodulator FSM + D2H of the bits: overlaps the next cascade launch
     hipEvent_t casc_done[2] = { nullptr, nullptr };   // y3[b] written
     hipEvent_t demod_done[2] = { nullptr, nullptr };  // y3[b] consumed
+    hipEvent_t fsm_done = nullptr; bool fsm_pending = false;   // word buffer consumed
     bool demod_pending[2] = { false, false };
     // device
     uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
@@ -192,6 +193,7 @@ static void free_handle(nvx_handle *h)
     }
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
+    if (h->fsm_done) hipEventDestroy(h->fsm_done);
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
@@ -199,7 +201,7 @@ static void free_handle(nvx_handle *h)
         if (r.h_bits) hipHostFree(r.h_bits);
         if (r.h_nbits) hipHostFree(r.h_nbits);
         if (r.done) hipEventDestroy(r.done);
-        for (int i = 0; i < 4; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
+        for (int i = 0; i < 6; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
     }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
@@ -267,6 +269,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipEventCreateWithFlags(&h->casc_done[i], hipEventDisableTiming));
         CR_TRY(hipEventCreateWithFlags(&h->demod_done[i], hipEventDisableTiming));
     }
+    CR_TRY(hipEventCreateWithFlags(&h->fsm_done, hipEventDisableTiming));
     std::vector<uint8_t> active(h->n_slots);
     for (int i = 0; i < h->n_slots; i++) active[i] = h->slots[i].active;
     CR_TRY(hipMalloc(&h->d_masks, h->n_streams));
@@ -287,7 +290,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipHostMalloc((void **)&r.h_bits, (size_t)h->n_slots * h->bits_cap, hipHostMallocDefault));
         CR_TRY(hipHostMalloc((void **)&r.h_nbits, (size_t)h->n_slots * sizeof(int), hipHostMallocDefault));
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        for (int i = 0; i < 4; i++) CR_TRY(hipEventCreate(&r.ev[i]));
+        for (int i = 0; i < 6; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
     if (cfg->wideband) {
         CR_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
@@ -328,6 +331,7 @@ extern "C" int nvx_reset(nvx_handle *h)
     h->collected = h->launched;
     h->g0 = 0;
     h->demod_pending[0] = h->demod_pending[1] = false;
+    h->fsm_pending = false;
     if (h->stream3) {
         HIP_TRY(hipStreamSynchronize(h->stream3));
         for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_whist[i], 0, (size_t)h->n_in * 40 * 4, h->stream));
@@ -387,11 +391,13 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     }
 
     const int yb = (int)(h->launched & 1);              // y3 buffer of this launch
-    // Measured (profiles/r01, DESIGN.md tuning log): running the demodulator on a second
-    // stream beside the NEXT cascade launch loses -- the persistent cascade grid owns every
-    // CU's LDS, so the demod workgroups only become resident as it drains.  Default: same stream.
-    static const bool overlap = getenv("NVX_OVERLAP") && atoi(getenv("NVX_OVERLAP")) == 1;
-    hipStream_t s2 = overlap ? h->stream2 : st;
+    // Where the demodulator runs (measured, DESIGN.md tuning log).  Its time-parallel front needs LDS, and the
+    // persistent cascade grid owns every CU's LDS: beside the NEXT cascade launch it only becomes resident as
+    // that drains (loses), so it stays on the cascade's stream.  The sequential FSM kernel is 64 waves without
+    // LDS and does run beside the next cascade (NVX_FSM_OVERLAP=1, second stream), but what it hides (0.34 ms)
+    // the cascade loses again (20.1 vs 19.8 ms): step time equal, so the default is one stream.
+    static const bool fsm_overlap = getenv("NVX_FSM_OVERLAP") && atoi(getenv("NVX_FSM_OVERLAP")) == 1;
+    hipStream_t s2 = fsm_overlap ? h->stream2 : st;
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
@@ -414,13 +420,20 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     if (h->cfg.wideband) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
     HIP_TRY(hipMemcpyAsync(h->h_status + (h->launched % RESULT_SLOTS), h->d_ctrl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
-    // demodulator + bit download on the second stream, behind this cascade only
-    HIP_TRY(hipStreamWaitEvent(s2, h->casc_done[yb], 0));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], s2));
-    HIP_TRY(nvx_launch_demod(&da, s2));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], s2));
-    HIP_TRY(hipEventRecord(h->demod_done[yb], s2));
+    // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
+    if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], st));
+    HIP_TRY(nvx_launch_demod_front(&da, st));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], st));
+    HIP_TRY(hipEventRecord(h->demod_done[yb], st));      // y3[yb] consumed
     h->demod_pending[yb] = true;
+    // FSM + bit download behind the front
+    if (s2 != st) HIP_TRY(hipStreamWaitEvent(s2, h->demod_done[yb], 0));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[4], s2));
+    HIP_TRY(nvx_launch_demod_fsm(&da, s2));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[5], s2));
+    HIP_TRY(hipEventRecord(h->fsm_done, s2));
+    h->fsm_pending = true;
     HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipEventRecord(r.done, s2));
@@ -444,7 +457,10 @@ static int collect_locked(nvx_handle *h)
             }
             if (r.timed) {
                 HIP_TRY(hipEventElapsedTime(&h->ms[0], r.ev[0], r.ev[1]));
+                float fsm_ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[2], r.ev[3]));
+                HIP_TRY(hipEventElapsedTime(&fsm_ms, r.ev[4], r.ev[5]));
+                h->ms[1] += fsm_ms;                       // "demodulator" = front + FSM
                 h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
             }
             std::atomic<int> bad_slot{ -1 };

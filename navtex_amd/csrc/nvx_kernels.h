@@ -82,7 +82,8 @@ extern "C" {
 #endif
 hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStream_t s);
 hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s);
-hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s);
+hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s);
+hipError_t nvx_launch_demod_fsm(const nvx_demod_args *a, hipStream_t s);
 hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s);
 double nvx_atan2_host(double y, double x);
 #ifdef __cplusplus

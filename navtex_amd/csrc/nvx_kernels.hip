@@ -903,11 +903,14 @@ extern "C" hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStr
     return hipGetLastError();
 }
 
-extern "C" hipError_t nvx_launch_demod(const nvx_demod_args *a, hipStream_t s)
+extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s)
 {
     hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(256), 0, s, *a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+extern "C" hipError_t nvx_launch_demod_fsm(const nvx_demod_args *a, hipStream_t s)
+{
     hipLaunchKernelGGL(nvx_demod_fsm, dim3((unsigned)((a->n_slots + 63) / 64)), dim3(64), 0, s, *a);
     return hipGetLastError();
 }
