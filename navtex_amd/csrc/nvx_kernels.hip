@@ -570,17 +570,22 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         // ---- class sum, decoder.C:181-197: ring positions c, c+9, ... ascending.
         // Position p holds the newest value kappa' <= kappa with kappa' = p (mod 567),
         // i.e. the value d = (kappa - p) mod 567 samples back.
+        // The order is a rotation of the time order: with d0 = (kappa - c) mod 567 and jw = d0 / 9 the terms are
+        // the samples d0, d0-9, ..., d0-9*jw back (ascending in time, stride 9), then those 558+r, ..., d0+9 back
+        // (r = d0 mod 9) -- two runs of one stride-9 walk through the time-ordered buffer, the second one starting
+        // 567 entries lower.  t_cb = (g of L = 0) - 574 mod 5103 (= 9 * 567) keeps the index arithmetic in 32 bits.
+        const unsigned t_cb = (unsigned)((gt % 5103u + (5103u - G_CB % 5103u)) % 5103u);
         for (int L = tid; L < tl; L += 256) {
-            const unsigned long long g = gt + L;
-            if (g >= G_CB) {
-                const unsigned long long kappa = g - 8;
-                const int c = (int)((g - G_CB) % 9);
-                int d = (int)((kappa - c) % 567);
+            if (gt + L >= G_CB) {
+                const unsigned u = t_cb + (unsigned)L;               // == g - 574 (mod 5103)
+                const unsigned c = u % 9u;
+                const int d0 = (int)((u + 566u - c) % 567u);         // (kappa - c) mod 567, kappa = g - 8
+                const int jw = d0 / 9;
+                const double *run1 = &s_C[567 + L - d0];             // terms j = 0 .. jw
+                const double *run2 = run1 - 567;                     // terms j = jw+1 .. 62
                 double temp = 0.0;
-                for (int j = 0; j < 63; j++) {
-                    temp += s_C[567 + L - d];
-                    d -= 9; if (d < 0) d += 567;
-                }
+#pragma unroll
+                for (int j = 0; j < 63; j++) temp += (j <= jw ? run1 : run2)[9 * j];
                 s_S[8 + L] = temp;
             } else {
                 s_S[8 + L] = 0.0;
