@@ -198,6 +198,10 @@ NVX_API void  nvx_enable_timing(nvx_handle *h, int enabled);
 /* sum of the event durations (ms) and number of timed launches collected since
  * the last reset of the statistics; reset != 0 clears them afterwards          */
 NVX_API int   nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, uint64_t *launches, int reset);
+/* self-test of the demodulator's bit-period transition table against the per-sample rule it is
+ * generated from (receiver/decoder.C:62-137, 202-249), on `periods` pseudo-random bit periods;
+ * returns the number of differences (0 = pass).  Host only, no device needed.                  */
+NVX_API int   nvx_fsm_selftest(uint32_t seed, int periods);
 /* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */
 NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
 /* debug tap: copy the 900 S/s FIR-cascade output of the LAST launch for one

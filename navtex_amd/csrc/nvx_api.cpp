@@ -23,6 +23,7 @@
 #include "navtex_amd.h"
 #include "nvx_internal.h"
 #include "nvx_kernels.h"
+#include "nvx_fsm.h"
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -107,6 +108,7 @@ struct nvx_handle {
     uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
     double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
     double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
+    uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
     unsigned short *d_words = nullptr;
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
     int *h_status = nullptr;           // pinned copy of the status word of the last launch
@@ -178,6 +180,58 @@ extern "C" void nvx_config_default(nvx_config *c)
     c->max_frames = 1; c->char_layer = 1; c->push_mode = 0;
 }
 
+// Bit-period transition table of the demodulator FSM, generated once from the per-sample rule (nvx_fsm.h).
+static const uint32_t *fsm_table_host()
+{
+    static const std::vector<uint32_t> table = [] {
+        std::vector<uint32_t> t(NVX_FSM_TABLE_ALLOC, 0u);
+        for (int p1 = 0; p1 < 9; p1++)
+            for (int so = 0; so < 10; so++)
+                for (int a = 0; a < 9; a++)
+                    for (int b = 0; b < 9; b++) t[NVX_FSM_KEY(p1, so, a, b)] = nvx_fsm_table_entry(p1, so, a, b);
+        return t;
+    }();
+    return table.data();
+}
+
+// Replays pseudo-random front-kernel words through the per-sample rule and through the table, and counts
+// differences in the decided bits and in the carried registers.  No device needed (tests/test_host_layer.py).
+extern "C" int nvx_fsm_selftest(uint32_t seed, int periods)
+{
+    const uint32_t *tab = fsm_table_host();
+    uint32_t x = seed ? seed : 1u;
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    // per-sample registers (the reference's variables) and per-period registers
+    int synced = 0, sync_off = 0, next_sync_off = 0, phase = -1, prev_a = -1;
+    nvx_fsm_regs r = { 0, NVX_FSM_UNSYNCED, 0, -1 };
+    const int lead = (int)(rnd() % 70u);                     // periods before the class sums are primed
+    int raw = (int)(rnd() % 9u), bad = 0;
+    for (int m = 0; m < periods; m++) {
+        const uint32_t u = rnd();
+        if (u % 7u == 0) raw = (int)((u >> 8) % 9u);           // timing jumps; otherwise it drifts or holds
+        else if (u % 7u == 1) raw = (raw + 1) % 9;
+        else if (u % 7u == 2) raw = (raw + 8) % 9;
+        const unsigned w = ((u >> 16) & 0x1ffu) | ((unsigned)(m < lead ? 15 : raw) << 12);
+        unsigned want = 0; int n_want = 0;
+        for (int k = 0; k < 9; k++) {
+            if (k == NVX_FSM_TIMING_SAMPLE) {
+                int offset;
+                const int have = nvx_fsm_timing((int)(w >> 12), &prev_a, &offset);
+                sync_off = (have && !synced) ? offset : sync_off;      // decoder.C:62-70
+                next_sync_off = have ? offset : next_sync_off;
+                synced = have ? 1 : synced;
+            }
+            if (nvx_fsm_bit_step(k, synced, &phase, &sync_off, next_sync_off)) { want |= ((w >> k) & 1u) << n_want; n_want++; }
+        }
+        int n_got;
+        const unsigned got = nvx_fsm_period(tab, w, &r, &n_got) & ((1u << n_got) - 1u);
+        if (n_got != n_want || got != want) bad++;
+        if (r.phase1 != phase + 1 || r.nso != next_sync_off || r.prev_offset != prev_a ||
+            (r.so != NVX_FSM_UNSYNCED) != (synced != 0) || (synced && r.so != sync_off)) bad++;
+    }
+    return bad;
+}
+
 static void free_handle(nvx_handle *h)
 {
     if (!h) return;
@@ -194,7 +248,7 @@ static void free_handle(nvx_handle *h)
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
-    hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
+    hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
         hipFree(r.d_bits); hipFree(r.d_nbits);
@@ -280,6 +334,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
     CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
+    CR_TRY(hipMalloc(&h->d_fsm_tab, NVX_FSM_TABLE_ALLOC * sizeof(uint32_t)));
+    CR_TRY(hipMemcpy(h->d_fsm_tab, fsm_table_host(), NVX_FSM_TABLE_ALLOC * sizeof(uint32_t), hipMemcpyHostToDevice));
     CR_TRY(hipMalloc(&h->d_words, (size_t)(h->y3_cap / 9) * h->n_slots * sizeof(unsigned short)));
     CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
     CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * sizeof(int), hipHostMallocDefault));
@@ -408,7 +464,7 @@ static int launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t f
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
-    da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.words = h->d_words;
+    da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
 
     // cascade on `st`: it may not overwrite y3[yb] before the demodulator of two launches ago has read it

@@ -48,6 +48,7 @@
 
 #include "nvx_tables.h"
 #include "nvx_atan2.h"
+#include "nvx_fsm.h"
 #include "nvx_synth.h"
 #include "nvx_kernels.h"
 
@@ -631,27 +632,31 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
 }
 
 // Sequential part: the timing slew limiter (decoder.C:217-249) and the bit FSM
-// (decoder.C:62-137), integers only, one lane per chain, branch-free.
-//
-// The reference's (status, burn_count, samplecount) triple only ever walks one
-// fixed path, so it is kept as a single phase counter:
-//   phase -1        STATUS_SYNCED_WAIT (or STATUS_INIT while synced == 0)
-//   phase 0, 1      the two burned samples (decoder.C:91-110; the sample that
-//                   matches the sync offset is itself the first of them)
-//   phase 2         the sample that flips to RECEIVING and is not used
-//   phase 3..7      the five accumulated samples; the decision falls on 7
-// The slew limiter's four-way branch is the rule: with diff = (argmax - prev)
-// mod 9, diff 1..4 -> prev+1, diff 5..8 -> prev-1 (same thing).
+// (decoder.C:62-137), integers only, one lane per chain.  Both are stated per
+// sample in nvx_fsm.h; the kernel advances a whole bit period at a time with
+// the transition table generated from that statement (29 KB, copied to LDS):
+// the dependent chain per period is the slew rule, one LDS lookup and a few
+// bit operations instead of nine sample steps.
 __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
 {
+    __shared__ uint32_t s_tab[NVX_FSM_TABLE_ALLOC];
+    {
+        const uint4 *src = (const uint4 *)a.fsm_table;
+        uint4 *dst = (uint4 *)s_tab;
+        for (int i = threadIdx.x; i < NVX_FSM_TABLE_ALLOC / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
     const int slot = blockIdx.x * 64 + threadIdx.x;
     const int nc = a.n_slots;
     if (slot >= nc) return;
     if (!a.slot_active[slot]) return;
     int *si = a.state_i;
 #define SI(f) si[(size_t)(f) * nc + slot]
-    int synced = SI(DI_SYNCED), sync_off = SI(DI_SYNC_OFF), next_sync_off = SI(DI_NEXT_SYNC_OFF);
-    int phase = SI(DI_PHASE), prev_offset = SI(DI_PREV_OFFSET);
+    nvx_fsm_regs r;
+    r.so = SI(DI_SYNCED) ? SI(DI_SYNC_OFF) : NVX_FSM_UNSYNCED;
+    r.nso = SI(DI_NEXT_SYNC_OFF);
+    r.phase1 = SI(DI_PHASE) + 1;
+    r.prev_offset = SI(DI_PREV_OFFSET);
 
     // decoded bits are packed ('B' = 1, LSB first) and stored one 32-bit word at a
     // time: byte stores would sit in front of every prefetched load in the in-order
@@ -672,35 +677,12 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
         for (int i = 0; i < 4; i++) { wcur[i] = wq[i]; if (m0 + 4 + i < periods) wq[i] = words[(size_t)(m0 + 4 + i) * nc]; }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const unsigned w = wcur[i];
-#pragma unroll
-            for (int k = 0; k < 9; k++) {         // local sample 9m+k; g mod 9 == k (g0 is a multiple of 9)
-                if (k == G_CSA % 9) {
-                    // ---- timing decision, decoder.C:202-249 (arg-max precomputed; 15 = not primed yet)
-                    const int raw = (int)(w >> 12);
-                    const bool have = raw != 15;
-                    const int diff = (raw - prev_offset + 9) % 9;
-                    int mi = raw;
-                    const bool slew = (prev_offset != -1) && (diff != 0);
-                    const int up = (prev_offset + 1) % 9, dn = (prev_offset + 8) % 9;
-                    mi = slew ? ((diff <= 4) ? up : dn) : mi;
-                    const int offset = (mi + 5) % 9;                                  // decoder.C:249
-                    prev_offset = have ? mi : prev_offset;
-                    sync_off = (have && !synced) ? offset : sync_off;                 // decoder.C:62-70
-                    next_sync_off = have ? offset : next_sync_off;
-                    synced = have ? 1 : synced;
-                }
-                // ---- bit FSM, decoder.C:73-137; bd_seq_nbr mod 9 = (k + 1) mod 9
-                const bool start = (phase < 0) && synced && (((k + 1) % 9) == sync_off);
-                phase = start ? 0 : ((phase >= 0) ? phase + 1 : phase);
-                const bool decide = phase == 7;
-                acc |= decide ? ((unsigned long long)((w >> k) & 1u) << nacc) : 0ull;
-                nacc += decide ? 1 : 0;
-                phase = decide ? -1 : phase;
-                sync_off = decide ? next_sync_off : sync_off;
-            }
+            int n;
+            const unsigned b = nvx_fsm_period(s_tab, wcur[i], &r, &n);
+            acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
+            nacc += n;
         }
-        // at most 5 bits per 4 periods: one store check per group keeps the sample steps branch-free
+        // at most 5 bits per 4 periods: one store check per group
         if (nacc >= 32) {
             if (nwords < cap_words) bits[nwords] = (unsigned)acc;
             nwords++; acc >>= 32; nacc -= 32;
@@ -709,8 +691,9 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     if (nacc > 0 && nwords < cap_words) bits[nwords] = (unsigned)acc;
 
     a.nbits[slot] = nwords * 32 + nacc;
-    SI(DI_SYNCED) = synced; SI(DI_SYNC_OFF) = sync_off; SI(DI_NEXT_SYNC_OFF) = next_sync_off;
-    SI(DI_PHASE) = phase; SI(DI_PREV_OFFSET) = prev_offset;
+    const int synced = r.so != NVX_FSM_UNSYNCED;
+    SI(DI_SYNCED) = synced; SI(DI_SYNC_OFF) = synced ? r.so : 0; SI(DI_NEXT_SYNC_OFF) = r.nso;
+    SI(DI_PHASE) = r.phase1 - 1; SI(DI_PREV_OFFSET) = r.prev_offset;
 #undef SI
 }
 

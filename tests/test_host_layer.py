@@ -131,3 +131,10 @@ def test_config0_wav_file_through_the_cpu_reference_path(nv, oracle, tmp_path):
         p.push(back[k:k + 65536])
     assert p.bits(0) == rec["bits518"] and [list(m) for m in p.messages] == rec["messages"]
     assert (518, "EA01", "ZCZC EA01\nTEST MESSAGE 123 OK\nNNNN\n") in p.messages
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 0xC0FFEE, 987654321])
+def test_demod_fsm_period_table_equals_the_per_sample_rule(nv, seed):
+    """The FSM kernel steps a bit period at a time through a table generated from the per-sample
+    statement of decoder.C:62-137 / 202-249; random words through both must agree (host code)."""
+    assert nv.lib.nvx_fsm_selftest(seed, 200000) == 0
