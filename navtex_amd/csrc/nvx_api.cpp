@@ -189,6 +189,8 @@ static const uint32_t *fsm_table_host()
             for (int so = 0; so < 10; so++)
                 for (int a = 0; a < 9; a++)
                     for (int b = 0; b < 9; b++) t[NVX_FSM_KEY(p1, so, a, b)] = nvx_fsm_table_entry(p1, so, a, b);
+        for (int prev1 = 0; prev1 < 10; prev1++)
+            for (int rawc = 0; rawc < 10; rawc++) t[NVX_FSM_TIMING_BASE + prev1 * 10 + rawc] = nvx_fsm_timing_entry(prev1, rawc);
         return t;
     }();
     return table.data();

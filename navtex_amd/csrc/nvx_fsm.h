@@ -18,10 +18,10 @@
  * period the bit FSM is a function of four small integers
  *     (phase + 1, sync_off or 9 = not synced yet, next_sync_off before the
  *      timing decision, next_sync_off after it)
- * so the kernel steps a whole period with one table lookup.  The table is
- * GENERATED from nvx_fsm_bit_step below -- the per-sample rule stays the only
- * statement of the behaviour -- and nvx_fsm_selftest() replays random input
- * through both.
+ * so the kernel steps a whole period with one table lookup (and a second, 100-entry
+ * one for the slew limiter).  Both tables are GENERATED from nvx_fsm_timing /
+ * nvx_fsm_bit_step below -- the per-sample rule stays the only statement of the
+ * behaviour -- and nvx_fsm_selftest() replays random input through both.
  */
 #ifndef NVX_FSM_H
 #define NVX_FSM_H
@@ -36,8 +36,9 @@
 
 #define NVX_FSM_TIMING_SAMPLE 6                 /* G_CSA mod 9 */
 #define NVX_FSM_UNSYNCED 9                      /* sync_off code: no timing decision yet */
-#define NVX_FSM_TABLE_SIZE (9 * 10 * 9 * 9)
-#define NVX_FSM_TABLE_ALLOC 7296                /* rounded up to whole 16-byte words */
+#define NVX_FSM_TABLE_SIZE (9 * 10 * 9 * 9)     /* bit FSM: one entry per (phase1, so, nso_old, nso_new)         */
+#define NVX_FSM_TIMING_BASE NVX_FSM_TABLE_SIZE  /* slew limiter: 10 x 10 entries (prev_offset + 1, raw or 9 = none) */
+#define NVX_FSM_TABLE_ALLOC 7392                /* 7290 + 100, rounded up to whole 16-byte words                 */
 
 /* table entry: bits 0-3 phase+1 after the period, 4-7 sync_off after it (never 9),
  * 8-9 number of decisions (0..2), 10-13 / 14-17 the samples k they fall on        */
@@ -63,6 +64,14 @@ NVX_FSM_HD int nvx_fsm_timing(int raw, int *prev_offset, int *offset)
     *offset = (mi + 5) % 9;                                   /* decoder.C:249 */
     *prev_offset = have ? mi : prev;
     return have;
+}
+
+/* Slew-limiter table entry: bits 0-3 prev_offset + 1 afterwards, 4-7 the new sync offset, 8 = decision made */
+NVX_FSM_HD uint32_t nvx_fsm_timing_entry(int prev1, int rawc)
+{
+    int prev = prev1 - 1, offset = 0;
+    const int have = nvx_fsm_timing(rawc == 9 ? 15 : rawc, &prev, &offset);
+    return (uint32_t)(prev + 1) | ((uint32_t)offset << 4) | ((uint32_t)have << 8);
 }
 
 /* One sample of the bit FSM (decoder.C:73-137); k = index of the sample in its bit period.
@@ -108,9 +117,11 @@ typedef struct nvx_fsm_regs {
  * Returns the decided bits in the low *n_out (0..2) positions, first decision lowest.       */
 NVX_FSM_HD unsigned nvx_fsm_period(const uint32_t *tab, unsigned w, nvx_fsm_regs *r, int *n_out)
 {
-    int offset;
-    const int have = nvx_fsm_timing((int)(w >> 12), &r->prev_offset, &offset);
-    const int nso_new = have ? offset : r->nso;
+    const unsigned raw = w >> 12;
+    const uint32_t t = tab[NVX_FSM_TIMING_BASE + (r->prev_offset + 1) * 10 + (int)(raw > 9u ? 9u : raw)];
+    const int have = (int)((t >> 8) & 1u);
+    r->prev_offset = (int)(t & 15u) - 1;
+    const int nso_new = have ? (int)((t >> 4) & 15u) : r->nso;
     /* unsynced and no decision this period either: nothing can happen */
     const int live = have | (r->so != NVX_FSM_UNSYNCED);
     const uint32_t e = tab[NVX_FSM_KEY(r->phase1, r->so, r->nso, nso_new)];

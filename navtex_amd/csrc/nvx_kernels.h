@@ -55,7 +55,7 @@ typedef struct {
     double *dstate;            /* [n_slots][NVX_DEMOD_DOUBLES]                         */
     int *state_i;              /* [field][n_slots]                                     */
     const uint32_t *fsm_table; /* NVX_FSM_TABLE_ALLOC entries (nvx_fsm.h), 16-byte aligned */
-    unsigned short *words;     /* [n3/9][n_slots] per-bit-period hand-over, front -> fsm */
+    unsigned short *words;     /* [n_slots][y3_cap/9] per-bit-period hand-over, front -> fsm (rows 16-byte aligned) */
     uint8_t *bits; int bits_cap; int *nbits;   /* bits: packed, B = 1, LSB first; bits_cap bytes (multiple of 4) per slot */
     double *dphi;              /* optional debug tap, same layout as y3 (or NULL)      */
 } nvx_demod_args;

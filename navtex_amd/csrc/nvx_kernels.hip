@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
                     if (v > temp_max) { temp_max = v; max_index = i; }
                 }
             }
-            a.words[(size_t)(ta / 9 + M) * a.n_slots + slot] = (unsigned short)(w | (max_index << 12));
+            a.words[(size_t)slot * (a.y3_cap / 9) + (ta / 9 + M)] = (unsigned short)(w | (max_index << 12));
         }
         __syncthreads();
         // ---- slide the histories to the front for the next tile / the next launch
@@ -666,23 +666,23 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     unsigned long long acc = 0;                   // pending bits, LSB first
     int nacc = 0, nwords = 0;                     // bits pending in acc (< 64), words already stored
     const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
-    const unsigned short *words = a.words + slot;
-    unsigned wq[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) wq[i] = (i < periods) ? words[(size_t)i * nc] : 0;
+    // one row of 16-bit words per chain: eight bit periods per 16-byte load, requested one group ahead
+    const uint4 *words = (const uint4 *)(a.words + (size_t)slot * (a.y3_cap / 9));
+    uint4 wnext = words[0];
 
-    for (int m0 = 0; m0 < periods; m0 += 4) {     // periods is a multiple of 32
-        unsigned wcur[4];
+    for (int m0 = 0; m0 < periods; m0 += 8) {     // periods is a multiple of 32
+        const uint4 wv = wnext;
+        if (m0 + 8 < periods) wnext = words[m0 / 8 + 1];
+        const unsigned wcur[8] = { wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16,
+                                   wv.z & 0xffffu, wv.z >> 16, wv.w & 0xffffu, wv.w >> 16 };
 #pragma unroll
-        for (int i = 0; i < 4; i++) { wcur[i] = wq[i]; if (m0 + 4 + i < periods) wq[i] = words[(size_t)(m0 + 4 + i) * nc]; }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 8; i++) {
             int n;
             const unsigned b = nvx_fsm_period(s_tab, wcur[i], &r, &n);
             acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
             nacc += n;
         }
-        // at most 5 bits per 4 periods: one store check per group
+        // at most 10 bits per 8 periods: one store check per group
         if (nacc >= 32) {
             if (nwords < cap_words) bits[nwords] = (unsigned)acc;
             nwords++; acc >>= 32; nacc -= 32;
