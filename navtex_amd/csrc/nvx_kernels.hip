@@ -494,7 +494,13 @@ enum { DI_SYNCED = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_PHASE, DI_PREV_OFFSET, D
 static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET &&
               DI_PHASE == NVX_DI_PHASE, "state layout");
 
+#ifndef NVX_FRONT_THREADS
+#define NVX_FRONT_THREADS 256
+#endif
+#ifndef DTL
 #define DTL 1152                         // time tile: 4 frames of 900 S/s samples (multiple of 9)
+#endif
+#define FRONT_SLIDE ((567 + NVX_FRONT_THREADS - 1) / NVX_FRONT_THREADS)
 #define G_DAB 8
 #define G_CB 574
 #define G_CSA 582
@@ -507,7 +513,7 @@ __device__ __forceinline__ double2 y3_at(const double2 *y3, const double *hist, 
     return r;
 }
 
-__global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
+__global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_args a)
 {
     __shared__ double s_dphi[8 + DTL];
     __shared__ double s_S[8 + DTL];
@@ -521,13 +527,13 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
     double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
     const double *hist = st + DS_Y3;                     // read in place: only the first 4 samples need it
     if (tid < 8) { s_dphi[tid] = st[DS_DPHI + tid]; s_S[tid] = st[DS_S + tid]; }
-    for (int i = tid; i < 567; i += 256) s_C[i] = st[DS_C + i];
+    for (int i = tid; i < 567; i += NVX_FRONT_THREADS) s_C[i] = st[DS_C + i];
     __syncthreads();
 
     for (int ta = 0; ta < a.n3; ta += DTL) {
         const int tl = min(DTL, a.n3 - ta);
         const unsigned long long gt = a.g0 + (unsigned long long)ta;     // g of L = 0
-        for (int L = tid; L < tl; L += 256) {
+        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             const int t = ta + L;
             // ---- discriminator, decoder.C:48-52
             const double2 s = y3[t];
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         }
         __syncthreads();
         // ---- transition correlator, decoder.C:157-177: mask[i] * dphi[g-8+i], i ascending
-        for (int L = tid; L < tl; L += 256) {
+        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             if (gt + L >= G_DAB) {
                 double temp = 0.0;
 #pragma unroll
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         // (r = d0 mod 9) -- two runs of one stride-9 walk through the time-ordered buffer, the second one starting
         // 567 entries lower.  t_cb = (g of L = 0) - 574 mod 5103 (= 9 * 567) keeps the index arithmetic in 32 bits.
         const unsigned t_cb = (unsigned)((gt % 5103u + (5103u - G_CB % 5103u)) % 5103u);
-        for (int L = tid; L < tl; L += 256) {
+        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             if (gt + L >= G_CB) {
                 const unsigned u = t_cb + (unsigned)L;               // == g - 574 (mod 5103)
                 const unsigned c = u % 9u;
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         // ---- one word per bit period: nine window decisions + the arg-max of the
         // timing evaluation (decoder.C:202-215: csa[i] = S(g-8+i), strict '>' from
         // -1.0 => first maximum wins), which falls on local sample 9m+6
-        for (int M = tid; M < tl / 9; M += 256) {
+        for (int M = tid; M < tl / 9; M += NVX_FRONT_THREADS) {
             unsigned w = 0;
 #pragma unroll
             for (int k = 0; k < 9; k++) w |= (unsigned)s_D[9 * M + k] << k;
@@ -615,20 +621,20 @@ __global__ __launch_bounds__(256) void nvx_demod_front(nvx_demod_args a)
         }
         __syncthreads();
         // ---- slide the histories to the front for the next tile / the next launch
-        double h_d = 0.0, h_s = 0.0, h_c[3];
+        double h_d = 0.0, h_s = 0.0, h_c[FRONT_SLIDE];
         if (tid < 8) { h_d = s_dphi[tl + tid]; h_s = s_S[tl + tid]; }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; h_c[k] = (i < 567) ? s_C[tl + i] : 0.0; }
+        for (int k = 0; k < FRONT_SLIDE; k++) { const int i = tid + NVX_FRONT_THREADS * k; h_c[k] = (i < 567) ? s_C[tl + i] : 0.0; }
         __syncthreads();
         if (tid < 8) { s_dphi[tid] = h_d; s_S[tid] = h_s; }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + 256 * k; if (i < 567) s_C[i] = h_c[k]; }
+        for (int k = 0; k < FRONT_SLIDE; k++) { const int i = tid + NVX_FRONT_THREADS * k; if (i < 567) s_C[i] = h_c[k]; }
         __syncthreads();
     }
 
     if (tid < 4 && a.n3 >= 4) { const double2 l = y3[a.n3 - 4 + tid]; st[DS_Y3 + 2 * tid] = l.x; st[DS_Y3 + 2 * tid + 1] = l.y; }
     if (tid < 8) { st[DS_DPHI + tid] = s_dphi[tid]; st[DS_S + tid] = s_S[tid]; }
-    for (int i = tid; i < 567; i += 256) st[DS_C + i] = s_C[i];
+    for (int i = tid; i < 567; i += NVX_FRONT_THREADS) st[DS_C + i] = s_C[i];
 }
 
 // Sequential part: the timing slew limiter (decoder.C:217-249) and the bit FSM
@@ -893,7 +899,7 @@ extern "C" hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStr
 
 extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s)
 {
-    hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(NVX_FRONT_THREADS), 0, s, *a);
     return hipGetLastError();
 }
 
