@@ -365,3 +365,44 @@ def test_capture_debug_recording_reproduces_the_input(nv, tmp_path):
     with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True) as p:
         assert p.decode_wav(path) == 6
         assert p.bits(0, 0) == live and len(live) > 100
+
+
+def test_two_receivers_two_capture_rings_one_handle(nv, oracle):
+    """Two SDRs on one GPU handle: each has its own ring and vendor thread (jittered callbacks,
+    different signals); a launch happens whenever both streams have a whole frame staged."""
+    import threading
+    import time
+    import signals
+    n = 10 * nv.FRAME_IN
+    sigs = [signals.stream_params(nv, seed, nv.RATE_IN)[0] for seed in (901, 902)]
+    iqs = [nv.synth_host(s, nv.RATE_IN, n) for s in sigs]
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True) as p:
+        caps = []
+        for s in range(2):
+            cap = C.c_void_p()
+            assert nv.lib.nvx_capture_start(p._h, s, 2.0, C.byref(cap)) == 0
+            caps.append(cap)
+        def vendor(s):
+            xi, xq = np.ascontiguousarray(iqs[s][:, 0]), np.ascontiguousarray(iqs[s][:, 1])
+            rng = np.random.default_rng(s)
+            pos = 0
+            while pos < n:
+                m = int(min(n - pos, rng.integers(500, 5000)))
+                # neither radio runs more than about a frame ahead of the other (they share a sample clock)
+                while pos - min(progress) > nv.FRAME_IN:
+                    time.sleep(0.0005)
+                nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, caps[s])
+                pos += m
+                progress[s] = pos
+        progress = [0, 0]
+        threads = [threading.Thread(target=vendor, args=(s,)) for s in range(2)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        for s in range(2):
+            r, d, c = _stats(nv, caps[s])
+            assert (r, d) == (n, 0)
+            assert nv.lib.nvx_capture_stop(caps[s]) == 0
+        for s in range(2):
+            ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(iqs[s])
+            assert p.bits(s, 0) == ref.bits(0) and len(ref.bits(0)) > 200
+        assert not np.array_equal(iqs[0], iqs[1])        # different signals (the first seconds are phasing either way)
