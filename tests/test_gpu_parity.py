@@ -248,3 +248,32 @@ def test_queue_handoff_stress(nv, oracle, raw):
                         assert np.array_equal(_u64(p.debug_y3(s, c)), _u64(ref.y3(c))), f"rep {rep} stream {s} chain {c}"
                         assert p.bits(s, c) == ref.bits(c)
     buf.free()
+
+
+@pytest.mark.parametrize("baud", [99.6, 100.35, 101.2])
+def test_baud_rate_drift_exercises_the_timing_slew(nv, oracle, baud):
+    """A transmitter whose clock is off makes the bit timing walk: the slew limiter steps every few
+    dozen bits and some bit periods hold two decisions or none.  Built with numpy (the library's generator
+    has a fixed 100 baud), both chains carry FSK with the same drift; bits bit-exact against the oracle and
+    the walk really happens (the bit count differs from the nominal 100 per second)."""
+    frames = 24
+    n = frames * nv.FRAME_IN
+    rng = np.random.default_rng(int(baud * 100))
+    t = np.arange(n)
+    iq = rng.normal(size=(n, 2)) * 300.0
+    for f0 in (14000.0, -14000.0):
+        bits = rng.integers(0, 2, int(n * baud / nv.RATE_IN) + 2)
+        shift = np.where(bits[(t * (baud / nv.RATE_IN)).astype(np.int64)] == 1, 85.0, -85.0)
+        ph = 2 * np.pi * np.cumsum((f0 + shift) / nv.RATE_IN)
+        iq += np.stack([np.cos(ph), np.sin(ph)], 1) * 6000.0
+    iq = np.clip(np.round(iq), -32768, 32767).astype(np.int16)
+    ref = oracle.Pipe(chain_mask=3, charlayer=False)
+    ref.push(iq)
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=5, push_mode=True, char_layer=False) as p:
+        p.push(0, iq)
+        p.flush()
+        for c in (0, 1):
+            want = ref.bits(c)
+            assert p.bits(0, c) == want, f"chain {c}"
+            nominal = frames * 32 - 66
+            assert abs(len(want) - nominal * baud / 100.0) < 6 and len(want) != nominal
