@@ -1,0 +1,130 @@
+// nvx_capture.cpp -- live-capture ring (header section B').
+#include "nvx_handle.h"
+
+// ===========================================================================
+// live-capture ring (section B'): capt_sched.c's producer / ring / consumer
+// ===========================================================================
+struct nvx_capture {
+    nvx_handle *h = nullptr;
+    int stream = 0;
+    std::vector<int16_t> ring;                  // interleaved I,Q (capt_sched.c:443: shorts)
+    size_t cap = 0;                             // complex samples
+    std::atomic<uint64_t> head{ 0 }, tail{ 0 }; // samples ever written / ever read
+    std::atomic<uint64_t> received{ 0 }, dropped{ 0 }, consumed{ 0 };
+    std::mutex prod_mu;                         // callback re-entrancy (capt_sched.c:111)
+    std::mutex cv_mu; std::condition_variable cv;
+    std::atomic<bool> stop{ false }, paused{ false };
+    std::atomic<int> error{ NVX_OK };
+    std::mutex rec_mu; nvx_wav *rec = nullptr;  // debug recording of what the consumer hands on (capt_sched.c:87-101, 516)
+    std::thread worker;
+};
+
+static void capture_consumer(nvx_capture *c)
+{
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(c->cv_mu);
+            c->cv.wait_for(lk, std::chrono::milliseconds(50), [&] {     // the reference polls every 50 ms (capt_sched.c:486)
+                return c->stop.load() || (!c->paused.load() && c->head.load() != c->tail.load());
+            });
+        }
+        if (c->paused.load() && !c->stop.load()) continue;
+        uint64_t t = c->tail.load(), hd = c->head.load();
+        while (t != hd) {                                                // contiguous spans, wrap split as capt_sched.c:494-503
+            size_t at = (size_t)(t % c->cap);
+            size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
+            int rc = nvx_push_iq(c->h, c->stream, c->ring.data() + 2 * at, n);
+            if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }
+            {
+                std::lock_guard<std::mutex> lk(c->rec_mu);
+                if (c->rec && nvx_wav_write(c->rec, c->ring.data() + 2 * at, n) != n) {     // disk full etc.: stop recording, keep decoding
+                    nvx_wav_close(c->rec); c->rec = nullptr;
+                }
+            }
+            t += n;
+            c->tail.store(t);
+            c->consumed.fetch_add(n);
+        }
+        if (c->stop.load() && c->head.load() == c->tail.load()) return;
+    }
+}
+
+extern "C" int nvx_capture_start(nvx_handle *h, int stream, double ring_seconds, nvx_capture **out)
+{
+    if (!h || !out || stream < 0 || stream >= h->n_in || !(ring_seconds > 0)) { nvx_set_error("nvx_capture_start: bad argument"); return NVX_ERR_ARG; }
+    if (!h->cfg.push_mode) { nvx_set_error("nvx_capture_start: handle needs push_mode"); return NVX_ERR_STATE; }
+    nvx_capture *c = new nvx_capture();
+    c->h = h; c->stream = stream;
+    const double rate = (h->cfg.raw_rate || h->cfg.wideband) ? (double)NVX_RATE_RAW : (double)NVX_RATE_IN;
+    c->cap = (size_t)(ring_seconds * rate);                              // capt_sched.c:443: rate * seconds
+    if (c->cap < 16) c->cap = 16;
+    c->ring.assign(2 * c->cap, 0);
+    c->worker = std::thread(capture_consumer, c);
+    *out = c;
+    return NVX_OK;
+}
+
+extern "C" void nvx_capture_callback(short *xi, short *xq, void *params, unsigned int numSamples, unsigned int reset, void *cbContext)
+{
+    (void)params; (void)reset;
+    nvx_capture *c = (nvx_capture *)cbContext;
+    if (!c || !xi || !xq) return;
+    std::lock_guard<std::mutex> lk(c->prod_mu);
+    c->received.fetch_add(numSamples);
+    const uint64_t hd = c->head.load();
+    const uint64_t room = c->cap - (hd - c->tail.load());
+    const size_t n = (size_t)std::min<uint64_t>(numSamples, room);
+    if (n < numSamples) c->dropped.fetch_add(numSamples - n);            // overrun: newest samples are dropped
+    for (size_t k = 0; k < n; k++) {                                     // interleave, capt_sched.c:120-129
+        const size_t at = (size_t)((hd + k) % c->cap);
+        c->ring[2 * at] = xi[k];
+        c->ring[2 * at + 1] = xq[k];
+    }
+    c->head.store(hd + n);
+    c->cv.notify_one();
+}
+
+extern "C" int nvx_capture_record(nvx_capture *c, const char *filename)
+{
+    if (!c) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->rec_mu);
+    if (c->rec) { nvx_wav_close(c->rec); c->rec = nullptr; }
+    if (!filename) return NVX_OK;
+    nvx_wav *w = nvx_wav_open(filename, NVX_WAV_OPEN_WRITE);
+    if (!w) { nvx_set_error("nvx_capture_record: %s", nvx_wav_err()); return NVX_ERR_IO; }
+    nvx_wav_set_format(w, 1);                                            // PrepWav, capt_sched.c:87-96
+    nvx_wav_set_num_channels(w, 2);
+    nvx_wav_set_sample_rate(w, (c->h->cfg.raw_rate || c->h->cfg.wideband) ? NVX_RATE_RAW : NVX_RATE_IN);
+    nvx_wav_set_sample_size(w, sizeof(short));
+    c->rec = w;
+    return NVX_OK;
+}
+
+extern "C" void nvx_capture_pause(nvx_capture *c, int paused)
+{
+    if (!c) return;
+    c->paused.store(paused != 0);
+    c->cv.notify_one();
+}
+
+extern "C" void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed)
+{
+    if (!c) return;
+    if (received) *received = c->received.load();
+    if (dropped) *dropped = c->dropped.load();
+    if (consumed) *consumed = c->consumed.load();
+}
+
+extern "C" int nvx_capture_stop(nvx_capture *c)
+{
+    if (!c) return NVX_ERR_ARG;
+    c->paused.store(false);
+    c->stop.store(true);
+    c->cv.notify_one();
+    if (c->worker.joinable()) c->worker.join();
+    int rc = c->error.load();
+    if (rc == NVX_OK) rc = nvx_flush(c->h);
+    if (c->rec) nvx_wav_close(c->rec);                                   // EndWav, capt_sched.c:98-101
+    delete c;
+    return rc;
+}

@@ -1,0 +1,123 @@
+// nvx_handle.h -- what the translation units of the host runtime share: the handle and its
+// helpers.  Internal; the public ABI is include/navtex_amd.h.
+#ifndef NVX_HANDLE_H
+#define NVX_HANDLE_H
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "navtex_amd.h"
+#include "nvx_internal.h"
+#include "nvx_kernels.h"
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            nvx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? NVX_ERR_NODEV : NVX_ERR_HIP; \
+        }                                                                                  \
+    } while (0)
+
+// NVX_OK after hipSetDevice(device); NVX_ERR_NODEV ("no CPU path") without a HIP device
+int nvx_select_device(int device);
+
+// ------------------------------------------------------------------ handle
+static const int RESULT_SLOTS = 4;
+
+struct Message { std::string bbbb, text; int freq; };
+
+struct Slot {                          // one (stream, chain)
+    bool active = false;
+    int label = 0;
+    std::string bits;                  // the most recent decoded bits (at most 2*NVX_BIT_HISTORY of them)
+    size_t base = 0;                   // absolute index (since create/reset) of bits[0]
+    size_t polled = 0;                 // nvx_poll_bits cursor, absolute
+    nvx_sitor *sitor = nullptr;
+    std::vector<Message> outbox;       // messages completed during a (possibly threaded) collect
+};
+
+struct Result {                        // one in-flight launch's bit output
+    uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
+    uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
+    hipEvent_t done = nullptr;
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
+    bool timed = false;
+    bool pending = false;
+};
+
+struct nvx_handle {
+    nvx_config cfg{};
+    int n_streams = 0, n_slots = 0, nch = 1;   // n_streams: 252 kS/s-path streams (8 per input in wideband mode)
+    int n_in = 0;                      // input streams the caller addresses (= n_streams unless wideband)
+    size_t bit_history = NVX_BIT_HISTORY;
+    bool cascade_raw = false;          // the cascade kernel's RAW switch (never set in wideband mode)
+    size_t frame_in = 0;               // complex input samples per frame at the input rate
+    // wideband mode: channeliser on stream3 into sub[b], overlapping the cascade of the previous launch
+    hipStream_t stream3 = nullptr;
+    uint32_t *d_sub[2] = { nullptr, nullptr };
+    uint32_t *d_whist[2] = { nullptr, nullptr };
+    hipEvent_t chan_done[2] = { nullptr, nullptr }, sub_free[2] = { nullptr, nullptr }, in_ready[2] = { nullptr, nullptr };
+    bool sub_busy[2] = { false, false };
+    uint64_t wide_launches = 0;
+    int y3_cap = 0, bits_cap = 0;
+    hipStream_t stream = nullptr;      // FIR cascade (or the caller's stream) and H2D staging
+    hipStream_t stream2 = nullptr;     // demodulator FSM + D2H of the bits: overlaps the next cascade launch
+    hipEvent_t casc_done[2] = { nullptr, nullptr };   // y3[b] written
+    hipEvent_t demod_done[2] = { nullptr, nullptr };  // y3[b] consumed
+    hipEvent_t fsm_done = nullptr; bool fsm_pending = false;   // word buffer consumed
+    bool demod_pending[2] = { false, false };
+    // device
+    uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
+    double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
+    double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
+    uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
+    unsigned short *d_words = nullptr;
+    int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
+    int *h_status = nullptr;           // pinned copy of the status word of the last launch
+    unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
+    Result res[RESULT_SLOTS];
+    uint64_t launched = 0, collected = 0;
+    int last_n3 = 0;
+    // timing
+    bool timing = false;
+    float ms[2] = { 0.f, 0.f };          // last collected launch
+    double ms_sum[2] = { 0.0, 0.0 };     // over all collected launches since the last stats reset
+    uint64_t ms_count = 0;
+    // host
+    std::vector<uint8_t> masks;
+    std::vector<Slot> slots;
+    std::vector<struct SinkCtx *> sinks;   // user pointers handed to the per-slot character layers
+    std::mutex mu;
+    // push mode staging: two pinned sets [n_streams][stage_cap] of packed IQ words
+    uint32_t *h_stage[2] = { nullptr, nullptr };
+    hipEvent_t stage_free[2] = { nullptr, nullptr };
+    bool stage_busy[2] = { false, false };
+    int cur = 0;
+    size_t stage_cap = 0;
+    std::vector<size_t> fill;
+    uint32_t *d_in = nullptr;
+};
+
+struct SinkCtx { nvx_handle *h; int stream; int slot; };
+
+// launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)
+int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
+                      bool input_on_stream3 = false);
+// wait for every launched block, append bits, run the character layer (handle locked)
+int nvx_collect_locked(nvx_handle *h);
+// bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries
+const uint32_t *nvx_fsm_table_host();
+
+#endif

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256) void nvx_synth_kernel(nvx_synth_args a)
 }
 
 // ===========================================================================
-// launchers (C linkage, called from nvx_api.cpp)
+// launchers (C linkage, called from the host runtime)
 // ===========================================================================
 // tuning switches for A/B runs (defaults are the shipped configuration)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }

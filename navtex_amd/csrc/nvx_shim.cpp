@@ -1,0 +1,99 @@
+// nvx_shim.cpp -- the reference-compatible surface (header sections A, B): the three symbols
+// capt_sched.c links against, the SDRplay-shaped stream callback, and the weak default add_message.
+#include "nvx_handle.h"
+
+// Default sink when nothing else in the program defines add_message (the reference's
+// message_store.c does): the database named by NAVTEX_AMD_DB, else stdout.
+extern "C" __attribute__((weak, visibility("default"))) int add_message(char *bbbb, char *message, int freq)
+{
+    static std::once_flag once;
+    static nvx_store *store = nullptr;
+    std::call_once(once, [] {
+        const char *path = getenv("NAVTEX_AMD_DB");
+        if (path && *path && nvx_store_open(path, 1, &store) != NVX_OK) {
+            fprintf(stderr, "navtex_amd: NAVTEX_AMD_DB=%s: %s\n", path, nvx_last_error());
+            abort();                             // a configured sink that cannot be opened must not lose messages quietly
+        }
+    });
+    if (store) return nvx_store_add_message(store, bbbb, message, freq);
+    printf("[navtex_amd] message freq=%d bbbb=%s\n%s", freq, bbbb, message);
+    fflush(stdout);
+    return 0;
+}
+
+// ===========================================================================
+// reference-compatible push surface + stream callback (sections A, B)
+// ===========================================================================
+static nvx_handle *g_shim = nullptr;
+static std::mutex g_shim_mu;                     // callback re-entrancy (capt_sched.c:111)
+static int16_t g_shim_buf[2 * 4096];
+static size_t g_shim_n = 0;
+
+static void shim_fatal(const char *what)
+{
+    fprintf(stderr, "navtex_amd: %s: %s\n", what, nvx_last_error());
+    abort();                                     // void reference entry points cannot report errors
+}
+
+static void shim_require(void)
+{
+    if (g_shim) return;
+    nvx_config c; nvx_config_default(&c);
+    c.n_streams = 1; c.raw_rate = 0; c.chain_mask = NVX_CHAIN_518 | NVX_CHAIN_490;   // nav_sched.C:10-17
+    c.max_frames = 4; c.char_layer = 1; c.push_mode = 1;
+    if (const char *d = getenv("NAVTEX_AMD_DEVICE")) c.device = atoi(d);
+    if (nvx_create(&c, &g_shim) != NVX_OK) shim_fatal("cannot create the GPU pipeline");
+}
+
+static void shim_drain(void)
+{
+    if (g_shim_n && nvx_push_iq(g_shim, 0, g_shim_buf, g_shim_n) != NVX_OK) shim_fatal("push failed");
+    g_shim_n = 0;
+}
+
+extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    shim_require();
+    g_shim_n = 0;
+    if (nvx_reset(g_shim) != NVX_OK) shim_fatal("reset failed");
+}
+
+extern "C" void init_fir2_wrapper(void)          // receiver/nav_sched.C:19-22
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    shim_require();                              // the object graph already exists; nothing else to wire
+}
+
+extern "C" void sample_in_1(double sample_I, double sample_Q)   // receiver/fir1cpp.C:80
+{
+    // capt_sched.c:511 passes (double) of int16 values; the cast back is exact
+    if (!g_shim) { std::lock_guard<std::mutex> lk(g_shim_mu); shim_require(); }
+    g_shim_buf[2 * g_shim_n] = (int16_t)sample_I;
+    g_shim_buf[2 * g_shim_n + 1] = (int16_t)sample_Q;
+    if (++g_shim_n == 4096) shim_drain();
+}
+
+extern "C" int nvx_shim_flush(void)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (!g_shim) { nvx_set_error("shim not initialised"); return NVX_ERR_STATE; }
+    shim_drain();
+    return nvx_flush(g_shim);
+}
+
+extern "C" size_t nvx_shim_bits(int chain, char *out, size_t cap)
+{
+    if (!g_shim) return 0;
+    return nvx_poll_bits(g_shim, 0, chain, out, cap);
+}
+
+extern "C" void nvx_StreamACallback(short *xi, short *xq, void *params, unsigned int numSamples,
+                                    unsigned int reset, void *cbContext)
+{
+    (void)params; (void)reset;                   // ignored by the reference too (capt_sched.c:105-148)
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    nvx_handle *h = (nvx_handle *)cbContext;
+    if (!h) { shim_require(); shim_drain(); h = g_shim; }
+    if (nvx_push_planar(h, 0, xi, xq, numSamples) != NVX_OK) shim_fatal("stream callback push failed");
+}
