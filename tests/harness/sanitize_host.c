@@ -1,5 +1,5 @@
 /* Sanitizer driver for the host-side C of the product (nvx_sitor.c, nvx_wav.c,
- * nvx_synth_host.c), built with -fsanitize=address,undefined by
+ * nvx_synth_host.c, nvx_store.c, nvx_fsm.h), built with -fsanitize=address,undefined by
  * tests/test_sanitizers.py.  Feeds bit strings from a file, random bits, WAV round
  * trips and generator calls; any memory error or UB aborts the process.          */
 #include <stdarg.h>
@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "navtex_amd.h"
+#include "nvx_fsm.h"
 
 void nvx_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 
@@ -68,6 +69,39 @@ int main(int argc, char **argv)
         short out[2 * 7001];
         if (nvx_synth_host(&st, NVX_RATE_IN, 123456789ull, 7001, out) != NVX_OK) return 5;
         if (nvx_synth_host(&st, NVX_RATE_RAW, 0, 7001, out) != NVX_OK) return 5;
+    }
+    /* 6. SQLite sink: schema, replace, purge, errors (argv[3] = database path) */
+    if (argc > 3) {
+        nvx_store *st = NULL;
+        if (nvx_store_open(argv[3], 1, &st) != NVX_OK) return 6;
+        nvx_store_set_time(st, 1741350896);
+        for (int i = 0; i < 40; i++) {
+            char id[8]; snprintf(id, sizeof id, "P%c%02d", 'A' + i % 5, i % 7);
+            if (nvx_store_add_message(st, id, "ZCZC\nTEXT\nNNNN\n", i & 1 ? 518 : 490) != 0) return 6;
+        }
+        if (nvx_store_add_message(st, "", "", 518) != 0 || nvx_store_add_message(NULL, "x", "y", 1) != -1) return 6;
+        nvx_store_set_time(st, 1741350896 + 80 * 3600);
+        if (nvx_store_purge(st, 0) <= 0) return 6;
+        unsigned long long a = 0, f = 0; nvx_store_stats(st, (uint64_t *)&a, (uint64_t *)&f);
+        if (a != 41 || f != 0) return 6;
+        nvx_store_close(st);
+        nvx_store *bad = NULL;
+        if (nvx_store_open("/nonexistent-dir/x.db", 1, &bad) == NVX_OK) return 6;
+    }
+    /* 7. demodulator FSM: every table entry, then random words through the per-sample rule and the tables */
+    {
+        static uint32_t tab[NVX_FSM_TABLE_ALLOC];
+        for (int p1 = 0; p1 < 9; p1++) for (int so = 0; so < 10; so++) for (int a = 0; a < 9; a++) for (int b = 0; b < 9; b++)
+            tab[NVX_FSM_KEY(p1, so, a, b)] = nvx_fsm_table_entry(p1, so, a, b);
+        for (int p = 0; p < 10; p++) for (int r = 0; r < 10; r++) tab[NVX_FSM_TIMING_BASE + p * 10 + r] = nvx_fsm_timing_entry(p, r);
+        nvx_fsm_regs r = { 0, NVX_FSM_UNSYNCED, 0, -1 };
+        unsigned y = 99; unsigned long bits = 0;
+        for (int m = 0; m < 200000; m++) {
+            y = y * 1664525u + 1013904223u;
+            unsigned w = ((y >> 8) & 0x1ffu) | ((m < 60 ? 15u : (y >> 20) % 9u) << 12);
+            int n; bits += nvx_fsm_period(tab, w, &r, &n) & ((1u << n) - 1u); bits += (unsigned long)n;
+        }
+        if (!bits) return 7;
     }
     printf("sanitize ok: %lu messages, %lu trace bytes\n", n_msgs, n_trace);
     return 0;

@@ -1,6 +1,6 @@
 """ASan + UBSan over the product's host-side C (CPU build only; GPU sanitizers are not
 available on the pool).  Inputs: every golden character-layer case, fuzz, WAV edge
-cases, generator sweeps -- see tests/harness/sanitize_host.c."""
+cases, generator sweeps, the SQLite sink, the demodulator FSM tables -- see tests/harness/sanitize_host.c."""
 import json
 import subprocess
 from pathlib import Path
@@ -16,12 +16,13 @@ def test_host_c_is_clean_under_asan_ubsan(nv, tmp_path):
     csrc = ROOT / "navtex_amd" / "csrc"
     subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
                     f"-I{ROOT / 'include'}", f"-I{csrc}", str(ROOT / "tests" / "harness" / "sanitize_host.c"),
-                    str(csrc / "nvx_sitor.c"), str(csrc / "nvx_wav.c"), str(csrc / "nvx_synth_host.c"), "-o", str(exe)], check=True)
+                    str(csrc / "nvx_sitor.c"), str(csrc / "nvx_wav.c"), str(csrc / "nvx_synth_host.c"), str(csrc / "nvx_store.c"),
+                    "-o", str(exe), "-ldl", "-lpthread"], check=True)
     lines = [cases.make_bits(nv, rec["spec"]) for rec in GOLD["charlayer"].values()]
     lines += [rec["bits518"] for rec in GOLD["iq"].values()]
     case_file = tmp_path / "cases.txt"
     case_file.write_text("\n".join(lines) + "\n")
-    out = subprocess.run([str(exe), str(case_file), str(tmp_path / "s.wav")], capture_output=True, text=True, timeout=600,
-                         env={"ASAN_OPTIONS": "detect_leaks=1", "PATH": "/usr/bin:/bin"})
+    out = subprocess.run([str(exe), str(case_file), str(tmp_path / "s.wav"), str(tmp_path / "s.db")], capture_output=True, text=True, timeout=600,
+                         env={"ASAN_OPTIONS": "detect_leaks=1", "PATH": "/usr/bin:/bin"})      # leaks inside libsqlite3 itself would show up too
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "sanitize ok" in out.stdout
