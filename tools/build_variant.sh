@@ -10,6 +10,7 @@ mkdir -p $R/tools/_bin
 O=$R/navtex_amd/_obj
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fvisibility=hidden -I$R/include -I$R/navtex_amd/csrc "$@" \
     -c $R/navtex_amd/csrc/nvx_kernels.hip -o $R/tools/_bin/nvx_kernels_$name.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $O/nvx_sitor.c.o $O/nvx_wav.c.o $O/nvx_synth_host.c.o $O/nvx_store.c.o \
-    $R/tools/_bin/nvx_kernels_$name.o $O/nvx_api.cpp.o -o $R/tools/_bin/libnavtex_amd_$name.so -lpthread -ldl
+objs=$(ls $O/*.o | grep -v nvx_kernels.hip.o)
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs $R/tools/_bin/nvx_kernels_$name.o \
+    -o $R/tools/_bin/libnavtex_amd_$name.so -lpthread -ldl
 echo $R/tools/_bin/libnavtex_amd_$name.so
