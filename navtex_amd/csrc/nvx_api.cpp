@@ -71,7 +71,7 @@ static void free_handle(nvx_handle *h)
         if (h->sub_free[i]) hipEventDestroy(h->sub_free[i]);
         if (h->in_ready[i]) hipEventDestroy(h->in_ready[i]);
     }
-    hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
+    hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate[0]); hipFree(h->d_cstate[1]); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
@@ -156,7 +156,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMalloc(&h->d_active, h->n_slots));
     CR_TRY(hipMemcpy(h->d_masks, h->masks.data(), h->n_streams, hipMemcpyHostToDevice));
     CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
-    CR_TRY(hipMalloc(&h->d_cstate, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
+    for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_cstate[i], (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
     CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
@@ -219,7 +219,7 @@ extern "C" int nvx_reset(nvx_handle *h)
         h->sub_busy[0] = h->sub_busy[1] = false;
         h->wide_launches = 0;
     }
-    HIP_TRY(hipMemsetAsync(h->d_cstate, 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_cstate[i], 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
     std::vector<int> ints((size_t)NVX_DEMOD_INTS * h->n_slots, 0);
@@ -282,7 +282,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
-    ca.state = h->d_cstate; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    ca.state_in = h->d_cstate[h->launched & 1]; ca.state_out = h->d_cstate[(h->launched + 1) & 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
     ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : 0;

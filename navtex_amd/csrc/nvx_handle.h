@@ -79,7 +79,8 @@ struct nvx_handle {
     hipEvent_t fsm_done = nullptr; bool fsm_pending = false;   // word buffer consumed
     bool demod_pending[2] = { false, false };
     // device
-    uint8_t *d_masks = nullptr, *d_active = nullptr, *d_cstate = nullptr;
+    uint8_t *d_masks = nullptr, *d_active = nullptr;
+    uint8_t *d_cstate[2] = { nullptr, nullptr };   // cascade state blocks: launch k reads [k & 1], writes [(k + 1) & 1]
     double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
     double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
     uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)

@@ -18,6 +18,17 @@
 #define NVX_UNIT_SPLIT 1
 #endif
 #define NVX_UNIT_PASSES (NVX_PASSES_PER_FRAME / NVX_UNIT_SPLIT)
+/* Independent units (launches with fewer streams than resident waves): a unit that is not the first of its
+ * stream in the launch rebuilds the filter histories from the input instead of waiting for its predecessor.
+ * Every value a real output uses must come from real samples in the reference's operation order:
+ *   y3[k >= 0] uses y2[>= -61]; the carried history needs y2[-70..-1]; y2[-70] uses u[-530..-484];
+ *   u[m] uses x[4m-33 .. 4m+3]  ->  x from -2153 on (252 kS/s samples before the unit).
+ * Nine passes (2304 samples) cover that, and with 96 mixer outputs and 64 FIR2 outputs "pending" at their start
+ * (zeros, consumed by runs whose outputs lie before the horizon) every batch counter is back at 0 exactly at the
+ * unit's first real pass: 96 + 9*64 = 672 = 3*224 = 6*112, 64 + 96 = 160 = 2*80; 576 = 0 mod 9 for the mixer. */
+#define NVX_PREROLL_PASSES 9
+#define NVX_PREROLL_U 96
+#define NVX_PREROLL_Y2 64
 #define NVX_UNIT_Y3 (NVX_Y3_PER_FRAME / NVX_UNIT_SPLIT)
 #define NVX_CASCADE_CTRL_INTS 2           /* [0] work-queue counter, [1] status (non-zero = spin timeout) */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
@@ -36,12 +47,14 @@ typedef struct {
     int n_frames;
     int n_streams;
     const uint8_t *chain_masks;
-    uint8_t *state;            /* [n_streams][NVX_CASCADE_STATE_BYTES]                 */
+    const uint8_t *state_in;   /* [n_streams][NVX_CASCADE_STATE_BYTES] left by the previous launch */
+    uint8_t *state_out;        /* same layout; hand-over inside this launch and to the next one   */
     double2 *y3;               /* [n_streams*2][y3_cap]                                */
     size_t y3_cap, y3_base;
     int *queue;                /* NVX_CASCADE_CTRL_INTS control ints followed by ...   */
     int *status;               /* = queue + 1                                          */
     int *done;                 /* = queue + 2: frames completed per stream             */
+    int independent;           /* set by the launcher: units do not wait for their predecessor (pre-roll instead) */
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid      */
 } nvx_cascade_args;
 

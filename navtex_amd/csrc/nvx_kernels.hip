@@ -248,16 +248,20 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
         const int chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
 
+        // independent units: rebuild the histories from the nine passes in front of the unit (nvx_kernels.h)
+        const bool preroll = a.independent && part > 0;
+        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
+        const int n_pass = pre + NVX_UNIT_PASSES;
         // the input does not depend on the predecessor: request the first pass(es) now
         const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) +
-                           (size_t)part * NVX_UNIT_PASSES * pass_stride + lane;
+                           ((size_t)part * NVX_UNIT_PASSES - (size_t)pre) * pass_stride + lane;
         u32x4 pfA[NPF], pfB[NPF];
         load_pass<RAW, NT>(pfA, src);
         if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
         const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
 
         // ------------------------------------------------------ wait for (stream, part-1)
-        if (part > 0) {
+        if (part > 0 && !a.independent) {
             int spins = 0, ok = 0;
             do {
                 int d = 0;
@@ -280,24 +284,41 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         }
 
         // ------------------------------------------------------ state in
-        double2 *st = (double2 *)(a.state + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+        // A stream's first unit of a launch reads the block the previous launch left (state_in); every unit
+        // writes state_out, which the host swaps with state_in between launches -- so a launch never reads
+        // and writes the same block through different units (the independent units run in any order).
+        double2 *st = (double2 *)(a.state_out + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+        const double2 *st_in = (part == 0) ? (const double2 *)(a.state_in + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
         NVX_WAVE_LDS_FENCE();
-        if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
-            int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
-            lds.X[r * XS + e] = state_load(st + lane);
-        }
+        if (!preroll) {
+            if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
+                int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
+                lds.X[r * XS + e] = state_load(st_in + lane);
+            }
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int ch = (NCH == 1) ? chain_of_slot0 : c;
-            const double2 *su = st + 36 + ch * (46 + 70);
-            if (lane < 46) lds.U[c][lane] = state_load(su + lane);
-            lds.Y2[c][lane] = state_load(su + 46 + lane);
-            if (lane < 6) lds.Y2[c][64 + lane] = state_load(su + 46 + 64 + lane);
+            for (int c = 0; c < NCH; c++) {
+                const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                const double2 *su = st_in + 36 + ch * (46 + 70);
+                if (lane < 46) lds.U[c][lane] = state_load(su + lane);
+                lds.Y2[c][lane] = state_load(su + 46 + lane);
+                if (lane < 6) lds.Y2[c][64 + lane] = state_load(su + 46 + 64 + lane);
+            }
+        } else {
+            const double2 zero = { 0.0, 0.0 };
+            if (lane < 36) lds.X[(lane & 3) * XS + (lane >> 2)] = zero;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                for (int i = lane; i < 46 + NVX_PREROLL_U; i += 64) lds.U[c][i] = zero;
+                for (int i = lane; i < 70 + NVX_PREROLL_Y2; i += 64) lds.Y2[c][i] = zero;
+            }
         }
         NVX_WAVE_LDS_FENCE();
 
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start)
-        int n_u = 0, n_y2 = 0, n3_done = 0, mixbase = ((part % NVX_UNIT_SPLIT) * (NVX_UNIT_PASSES * 64)) % NVX_MIX_N;
+        // (the pre-roll starts 576 = 0 mod 9 outputs earlier: same index)
+        int n_u = preroll ? NVX_PREROLL_U : 0, n_y2 = preroll ? NVX_PREROLL_Y2 : 0, n3_done = 0;
+        int mixbase = ((part % NVX_UNIT_SPLIT) * (NVX_UNIT_PASSES * 64)) % NVX_MIX_N;
+        bool emit = !preroll;                            // FIR3 outputs of the pre-roll are not written
         const size_t y3_row0 = (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_UNIT_Y3;
 
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 }
             }
             // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
-            if (pass + PFD < NVX_UNIT_PASSES) load_pass<RAW, NT>(pf, nxt);
+            if (pass + PFD < n_pass) load_pass<RAW, NT>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
 
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                         double acc = 0.0;
 #pragma unroll
                         for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
-                        if (f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
+                        if (emit && f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
                             double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + f3o));
                             out[comp] = acc;
                         }
@@ -424,27 +445,35 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         };
 
         if (PFD == 2) {
-            for (int pass = 0; pass < NVX_UNIT_PASSES; pass += 2) {
+            for (int pass = 0; pass < n_pass; pass += 2) {
+                if (pass == pre) { emit = true; n3_done = 0; }
                 body(pfA, pass);
-                if (pass + 1 < NVX_UNIT_PASSES) body(pfB, pass + 1);
+                if (pass + 1 == pre) { emit = true; n3_done = 0; }
+                if (pass + 1 < n_pass) body(pfB, pass + 1);
             }
         } else {
-            for (int pass = 0; pass < NVX_UNIT_PASSES; pass++) body(pfA, pass);
+            for (int pass = 0; pass < n_pass; pass++) {
+                if (pass == pre) { emit = true; n3_done = 0; }
+                body(pfA, pass);
+            }
         }
 
         // ------------------------------------------------------ state out
+        // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
-        if (lane < 36) {
-            int e = lane >> 2, r = lane & 3;
-            state_store(st + lane, lds.X[r * XS + e]);
-        }
+        if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) {
+            if (lane < 36) {
+                int e = lane >> 2, r = lane & 3;
+                state_store(st + lane, lds.X[r * XS + e]);
+            }
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int ch = (NCH == 1) ? chain_of_slot0 : c;
-            double2 *su = st + 36 + ch * (46 + 70);
-            if (lane < 46) state_store(su + lane, lds.U[c][lane]);
-            state_store(su + 46 + lane, lds.Y2[c][lane]);
-            if (lane < 6) state_store(su + 46 + 64 + lane, lds.Y2[c][64 + lane]);
+            for (int c = 0; c < NCH; c++) {
+                const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                double2 *su = st + 36 + ch * (46 + 70);
+                if (lane < 46) state_store(su + lane, lds.U[c][lane]);
+                state_store(su + 46 + lane, lds.Y2[c][lane]);
+                if (lane < 6) state_store(su + 46 + 64 + lane, lds.Y2[c][64 + lane]);
+            }
         }
         // publish: the state stores (write-through, sc1) have completed at device level once vmcnt is 0; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -452,7 +481,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        if (lane == 0) __hip_atomic_store(a.done + stream, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !a.independent) __hip_atomic_store(a.done + stream, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -870,7 +899,13 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     const int resident = n_cus * per_cu;
     const long long units = (long long)a->n_streams * a->n_frames * NVX_UNIT_SPLIT;
     const unsigned grid = (unsigned)(units < resident ? units : resident);
-    hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, *a);
+    // Fewer streams than resident waves: the units of one stream would run one after the other and most of the
+    // chip would idle.  Then every unit rebuilds its filter histories from the nine passes in front of it
+    // (+2.9 % input) and all of them run at once.  NVX_INDEPENDENT=0/1 forces the choice (tests, A/B runs).
+    nvx_cascade_args args = *a;
+    static const int force = env_int("NVX_INDEPENDENT", -1);
+    args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames * NVX_UNIT_SPLIT > 1);
+    hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, args);
     return hipGetLastError();
 }
 

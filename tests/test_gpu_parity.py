@@ -2,6 +2,8 @@
 same seeded inputs.  Bar: 900 S/s FIR output bit-exact (fp64 bit patterns),
 'B'/'Y' bits and decoded messages identical; delta-phi within 1 ulp of the
 oracle's glibc atan2 (tolerance explained in DESIGN.md, "atan2")."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -277,3 +279,46 @@ def test_baud_rate_drift_exercises_the_timing_slew(nv, oracle, baud):
             assert p.bits(0, c) == want, f"chain {c}"
             nominal = frames * 32 - 66
             assert abs(len(want) - nominal * baud / 100.0) < 6 and len(want) != nominal
+
+
+def test_dependent_and_independent_units_agree_bit_for_bit(nv, tmp_path):
+    """The cascade has two ways to carry filter state across the frames of a launch: hand it from unit
+    to unit (many streams) or let every unit rebuild it from the nine passes in front of it (few
+    streams; chosen automatically).  Forced either way in a subprocess, the 900 S/s output and the bits
+    of a 7-frame launch + a 3-frame launch are identical, for both input rates and both kernels."""
+    import hashlib, subprocess, sys, os
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv, signals
+h = hashlib.sha256()
+for raw in (False, True):
+    for masks in ([1, 2, 1], [3, 1, 3]):
+        rate = nv.RATE_RAW if raw else nv.RATE_IN
+        frame = nv.FRAME_RAW if raw else nv.FRAME_IN
+        streams = [signals.stream_params(nv, 500 + s, rate)[0] for s in range(3)]
+        pitch = 10 * frame
+        buf = nv.DeviceBuffer(3 * pitch * 4)
+        nv.synth_device(streams, rate, pitch, buf, pitch)
+        with nv.Pipeline(n_streams=3, raw_rate=raw, chain_masks=masks, max_frames=7, char_layer=False) as p:
+            p.process_resident(buf, pitch, 0, 7); p.fetch()
+            for s in range(3):
+                for c in range(2):
+                    if (masks[s] >> c) & 1: h.update(p.debug_y3(s, c).tobytes())
+            p.process_resident(buf, pitch, 7, 3); p.fetch()
+            for s in range(3):
+                for c in range(2):
+                    h.update(p.bits(s, c).encode())
+                    if (masks[s] >> c) & 1: h.update(p.debug_y3(s, c).tobytes())
+        buf.free()
+print(h.hexdigest())
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    digests = []
+    for mode in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, NVX_INDEPENDENT=mode))
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] and len(digests[0]) == 64
