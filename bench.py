@@ -316,6 +316,7 @@ def main():
     pipe.fetch()
     pipe.enable_timing(True)
     pipe.kernel_time_stats(0, reset=True)
+    pipe.wait_stats(reset=True)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -330,6 +331,7 @@ def main():
 
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
+    w_polls, w_units, w_launches = pipe.wait_stats()
     total_bits = sum(pipe.bit_count(s, 0) for s in range(0, S, max(1, S // 64)))
 
     if rank == 0:
@@ -361,7 +363,11 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_step,
                          "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),
-                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3)},
+                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
+                         # hand-over of filter state between the frames of a stream: share of units that had to
+                         # wait for their predecessor and the average wait of those (one poll ~ 1 us)
+                         "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4),
+                                     "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)}},
             "cpu_baseline": cpu,
             "parity": parity,
             "hbm_gbs_whole_job": round(world * bytes_per_step * args.steps / elapsed / 1e9, 1),

@@ -198,6 +198,9 @@ NVX_API void  nvx_enable_timing(nvx_handle *h, int enabled);
 /* sum of the event durations (ms) and number of timed launches collected since
  * the last reset of the statistics; reset != 0 clears them afterwards          */
 NVX_API int   nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, uint64_t *launches, int reset);
+/* hand-over statistics of the FIR-cascade work queue over the collected launches: how many units had to
+ * wait for the previous frame of their stream, and how many polls (about 1 us each) they spent waiting  */
+NVX_API int   nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *units_waited, uint64_t *launches, int reset);
 /* self-test of the demodulator's bit-period transition table against the per-sample rule it is
  * generated from (receiver/decoder.C:62-137, 202-249), on `periods` pseudo-random bit periods;
  * returns the number of differences (0 = pass).  Host only, no device needed.                  */

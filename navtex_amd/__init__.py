@@ -226,6 +226,12 @@ class Pipeline:
         self._bits.clear()
         self.messages.clear()
 
+    def wait_stats(self, reset: bool = False) -> Tuple[int, int, int]:
+        """(polls, units that waited, launches) of the cascade's unit hand-over since the last reset."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(lib.nvx_cascade_wait_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_wait_stats")
+        return a.value, b.value, c.value
+
     def enable_timing(self, on: bool = True) -> None:
         lib.nvx_enable_timing(self._h, int(on))
 

@@ -164,8 +164,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_fsm_tab, nvx_fsm_table_host(), NVX_FSM_TABLE_ALLOC * sizeof(uint32_t), hipMemcpyHostToDevice));
     CR_TRY(hipMalloc(&h->d_words, (size_t)(h->y3_cap / 9) * h->n_slots * sizeof(unsigned short)));
     CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
-    CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * sizeof(int), hipHostMallocDefault));
-    memset(h->h_status, 0, RESULT_SLOTS * sizeof(int));
+    CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * 3 * sizeof(int), hipHostMallocDefault));
+    memset(h->h_status, 0, RESULT_SLOTS * 3 * sizeof(int));
     for (auto &r : h->res) {
         CR_TRY(hipMalloc(&r.d_bits, (size_t)h->n_slots * h->bits_cap));
         CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
@@ -299,7 +299,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     HIP_TRY(nvx_launch_cascade(&ca, h->cascade_raw, h->nch, st));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
     if (h->cfg.wideband) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
-    HIP_TRY(hipMemcpyAsync(h->h_status + (h->launched % RESULT_SLOTS), h->d_ctrl + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->h_status + 3 * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
     // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
     if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
@@ -332,7 +332,9 @@ int nvx_collect_locked(nvx_handle *h)
         Result &r = h->res[h->collected % RESULT_SLOTS];
         if (r.pending) {
             HIP_TRY(hipEventSynchronize(r.done));
-            if (h->h_status[h->collected % RESULT_SLOTS] != 0) {
+            const int *stat = h->h_status + 3 * (h->collected % RESULT_SLOTS);
+            h->wait_polls += (uint64_t)(unsigned)stat[1]; h->wait_units += (uint64_t)(unsigned)stat[2]; h->wait_launches++;
+            if (stat[0] != 0) {
                 nvx_set_error("FIR cascade work queue: a wait on the previous frame of a stream timed out");
                 return NVX_ERR_HIP;
             }
@@ -446,6 +448,17 @@ extern "C" int nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, u
     if (sum_ms) *sum_ms = h->ms_sum[which];
     if (launches) *launches = h->ms_count;
     if (reset) { h->ms_sum[0] = h->ms_sum[1] = 0.0; h->ms_count = 0; }
+    return NVX_OK;
+}
+
+extern "C" int nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *units_waited, uint64_t *launches, int reset)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (polls) *polls = h->wait_polls;
+    if (units_waited) *units_waited = h->wait_units;
+    if (launches) *launches = h->wait_launches;
+    if (reset) h->wait_polls = h->wait_units = h->wait_launches = 0;
     return NVX_OK;
 }
 

@@ -86,7 +86,8 @@ struct nvx_handle {
     uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
     unsigned short *d_words = nullptr;
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
-    int *h_status = nullptr;           // pinned copy of the status word of the last launch
+    int *h_status = nullptr;           // pinned copies of {status, wait polls, units that waited} per result slot
+    uint64_t wait_polls = 0, wait_units = 0, wait_launches = 0;   // accumulated at collect
     unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
     Result res[RESULT_SLOTS];
     uint64_t launched = 0, collected = 0;

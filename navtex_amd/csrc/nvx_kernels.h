@@ -30,7 +30,8 @@
 #define NVX_PREROLL_U 96
 #define NVX_PREROLL_Y2 64
 #define NVX_UNIT_Y3 (NVX_Y3_PER_FRAME / NVX_UNIT_SPLIT)
-#define NVX_CASCADE_CTRL_INTS 2           /* [0] work-queue counter, [1] status (non-zero = spin timeout) */
+#define NVX_CASCADE_CTRL_INTS 4           /* [0] work-queue counter, [1] status (non-zero = spin timeout),  */
+                                         /* [2] polls spent waiting for a predecessor, [3] units that waited */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
  * outputs and 70 FIR2 outputs, all fp64 pairs                                 */
 #define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70))

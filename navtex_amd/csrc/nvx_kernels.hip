@@ -270,6 +270,10 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 ok = d >= part;
                 if (!ok) __builtin_amdgcn_s_sleep(32);
             } while (!ok && ++spins < NVX_SPIN_LIMIT);
+            if (spins > 0 && lane == 0) {                // instrumentation: how often, and how long, a hand-over was waited for
+                __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (!ok) {                                   // give up loudly rather than hang the GPU
                 if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
