@@ -26,14 +26,16 @@
 //     of one stream) from an atomic queue; every input byte is read from HBM
 //     exactly once, no halo is re-read; filter histories live in LDS between
 //     passes and travel between units / launches through a state block in HBM
-//     (agent-scope release / acquire, see the comment above the kernel);
+//     (agent-scope atomic accesses, no cache-wide fences; or, with few streams,
+//     are rebuilt by every unit from a nine-pass pre-roll -- see the comments
+//     above the kernel and in nvx_kernels.h);
 //   * a pass = 64 FIR1 outputs = 256 samples @252 kS/s = 2048 raw samples =
 //     8 KiB: eight fully coalesced 1-KiB global_load_dwordx4 per wave, issued
 //     one pass ahead into registers (prefetch) so HBM latency hides behind the
 //     fp64 work of the current pass;
-//   * stage 0 sums 8 raw samples with v_dot2c_i32_i16 (sign-extend + add in
-//     one op) and one DPP lane-pair exchange; each lane converts one component
-//     to fp64 and writes it to the LDS window;
+//   * stage 0 sums 8 raw samples with SDWA half-word pair adds (sign-extend +
+//     add of two samples in one op) and one DPP lane-pair exchange; each lane
+//     converts one component to fp64 and writes it to the LDS window;
 //   * the 252 kS/s window is kept polyphase-split (4 arrays of {I,Q} doubles)
 //     so that lane k's tap reads are consecutive 16-byte words: every
 //     ds_read_b128 / ds_write_b64 of FIR1 / stage 0 is bank-conflict free;
