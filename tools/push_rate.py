@@ -27,5 +27,8 @@ def run(n_streams, raw, frames_per_push, pushes):
 if __name__ == "__main__":
     run(1, False, 1, 20)
     run(1, True, 1, 20)
+    run(1, False, 24, 5)          # multi-frame pushes of one stream: the frames of a launch run in parallel
+    run(1, True, 12, 5)
+    run(8, True, 12, 4)
     run(64, True, 2, 6)
     run(256, True, 2, 3)
