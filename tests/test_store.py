@@ -124,3 +124,20 @@ def test_weak_add_message_writes_to_NAVTEX_AMD_DB(nv, tmp_path):
     env = dict(os.environ, NAVTEX_AMD_DB=db)
     subprocess.run([sys.executable, "-c", code, str(ROOT / "navtex_amd" / "libnavtex_amd.so")], check=True, env=env)
     assert [(r[0], r[1], r[4]) for r in rows(db)] == [("PA77", "ZCZC PA77\nVIA WEAK SINK\nNNNN\n", 490)]
+
+
+def test_one_store_shared_by_several_threads(nv, tmp_path):
+    """Several handles (threads) may share one store: every message arrives, none twice."""
+    import threading
+    db = str(tmp_path / "Navtex.db")
+    with nv.Store(db) as st:
+        st.set_time(T0)
+        def worker(k):
+            for i in range(25):
+                assert st.add_message(f"{chr(65 + k)}A{i:02d}", f"ZCZC {k} {i}\nNNNN\n", 518 if k & 1 else 490) == 0
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        assert st.stats() == (150, 0)
+    got = rows(db, "select bbbb from messages order by bbbb")
+    assert len(got) == 150 and len(set(got)) == 150
