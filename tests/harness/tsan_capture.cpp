@@ -1,0 +1,82 @@
+// ThreadSanitizer driver for the live-capture ring (navtex_amd/csrc/nvx_capture.cpp) without a GPU:
+// the ring, its producer callback, the consumer thread, pause / overrun accounting and the debug
+// recording run for real; the GPU pipeline behind nvx_push_iq / nvx_flush is replaced by a checker
+// that verifies the consumer hands on exactly the samples that were accepted, in order.
+// Built by tests/test_sanitizers.py with -fsanitize=thread.
+#include "nvx_handle.h"
+
+#include <chrono>
+
+static std::atomic<uint64_t> g_pushed{ 0 }, g_bad{ 0 };
+static uint64_t g_expect = 0;                    // next sample index the checker expects (consumer thread only)
+static std::vector<uint64_t> g_gaps;             // sample indices dropped by the producer, in order (under g_mu)
+static std::atomic<size_t> g_ngaps{ 0 };         // == g_gaps.size()
+static size_t g_gap_pos = 0;                     // gaps already skipped (consumer thread only)
+static std::mutex g_mu;
+
+extern "C" void nvx_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+
+// sample n carries I = low 15 bits of n, Q = next 15 bits: the checker recomputes n
+static inline void encode(uint64_t n, short *i, short *q) { *i = (short)(n & 0x7fff); *q = (short)((n >> 15) & 0x7fff); }
+
+extern "C" int nvx_push_iq(nvx_handle *, int, const int16_t *iq, size_t n)
+{
+    for (size_t k = 0; k < n; k++) {
+        if (g_ngaps.load() > g_gap_pos) {           // dropped samples are rare: take the lock only then
+            std::lock_guard<std::mutex> lk(g_mu);
+            while (g_gap_pos < g_gaps.size() && g_gaps[g_gap_pos] == g_expect) { g_gap_pos++; g_expect++; }
+        }
+        const uint64_t got = (uint64_t)(uint16_t)iq[2 * k] | ((uint64_t)(uint16_t)iq[2 * k + 1] << 15);
+        if (got != (g_expect & 0x3fffffff)) g_bad++;
+        g_expect++;
+    }
+    g_pushed += n;
+    return NVX_OK;
+}
+extern "C" int nvx_flush(nvx_handle *) { return NVX_OK; }
+
+int main(int argc, char **argv)
+{
+    nvx_handle h;                                  // only cfg / n_in are read by the capture code
+    h.cfg.push_mode = 1; h.cfg.raw_rate = 0; h.cfg.wideband = 0; h.n_in = 1;
+    nvx_capture *cap = nullptr;
+    if (nvx_capture_start(&h, 0, 0.02, &cap) != NVX_OK) return 2;      // 5040-sample ring: wraps constantly
+    if (argc > 1 && nvx_capture_record(cap, argv[1]) != NVX_OK) return 3;
+
+    const uint64_t total = 200000;
+    std::thread vendor([&] {                      // the SDR library's callback thread
+        std::vector<short> xi(4096), xq(4096);
+        uint64_t n = 0; unsigned x = 1;
+        while (n < total) {
+            x = x * 1664525u + 1013904223u;
+            unsigned m = 1 + (x >> 20) % 3000; if (n + m > total) m = (unsigned)(total - n);
+            for (unsigned k = 0; k < m; k++) encode(n + k, &xi[k], &xq[k]);
+            uint64_t r0, d0, c0; nvx_capture_stats(cap, &r0, &d0, &c0);
+            nvx_capture_callback(xi.data(), xq.data(), nullptr, m, 0, cap);
+            uint64_t r1, d1, c1; nvx_capture_stats(cap, &r1, &d1, &c1);
+            if (d1 > d0) {                        // the newest (d1 - d0) samples of this block were dropped
+                std::lock_guard<std::mutex> lk(g_mu);
+                for (uint64_t k = m - (d1 - d0); k < m; k++) g_gaps.push_back(n + k);
+                g_ngaps.store(g_gaps.size());
+            }
+            n += m;
+            if ((x >> 8) % 7 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    });
+    std::thread meddler([&] {                     // pauses and resumes the consumer: provokes overruns
+        for (int i = 0; i < 12; i++) {
+            nvx_capture_pause(cap, 1); std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            nvx_capture_pause(cap, 0); std::this_thread::sleep_for(std::chrono::milliseconds(3));
+        }
+    });
+    vendor.join(); meddler.join();
+    uint64_t rx, dropped, used;
+    nvx_capture_stats(cap, &rx, &dropped, &used);
+    if (nvx_capture_stop(cap) != NVX_OK) return 4;
+    const uint64_t pushed = g_pushed.load();
+    printf("received %llu dropped %llu pushed %llu bad %llu\n", (unsigned long long)rx, (unsigned long long)dropped,
+           (unsigned long long)pushed, (unsigned long long)g_bad.load());
+    if (rx != total || pushed + dropped != total || g_bad.load() != 0) return 5;
+    printf("tsan capture ok\n");
+    return 0;
+}
