@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off endurance run: the full-size batch (4096 streams x 12 frames) fed N times in a row WITHOUT reset
+"""One-off endurance run (soak_long_run.py [N] [streams] [frames]): the batch (default 4096 streams x 12 frames) fed N times in a row WITHOUT reset
 (38 minutes of signal per stream at N = 600, state carried through every launch), then four streams compared
 with the oracle fed the same N repetitions: total bit count and the retained bit history must be identical."""
 import sys, time
@@ -11,12 +11,13 @@ import navtex_amd as nv, oracle_binding as ob, signals
 from concurrent.futures import ThreadPoolExecutor
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-S, F = 4096, 12
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 4096       # few streams -> the independent-unit form of the cascade
+F = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 pitch = F * nv.FRAME_RAW
 buf = nv.DeviceBuffer(S * pitch * 4)
 streams = [signals.stream_params(nv, s, nv.RATE_RAW)[0] for s in range(S)]
 nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
-check = (0, 1234, 2815, 4095)
+check = sorted({0, S // 3, (2 * S) // 3, S - 1})
 t0 = time.time()
 with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F, char_layer=True) as p:
     for i in range(N):
