@@ -1,4 +1,5 @@
-// nvx_kernels.hip -- gfx950 kernels of the NAVTEX receive path.
+// nvx_cascade.hip -- the roofline kernel of the NAVTEX receive path (gfx950).  The other kernels:
+// nvx_demod.hip, nvx_channelise.hip, nvx_synth.hip.
 //
 //   nvx_fir_cascade<RAW, NCH, PFD, NT>   int16 IQ in HBM -> 900 S/s complex fp64 per chain
 //        stage 0 (/8 integer, build-owned, RAW only)
@@ -43,24 +44,13 @@
 //     (struct Geo below); a frame of 32 bit periods = 315 passes is a whole
 //     number of every batch, after which every decimation counter, the mixer
 //     index and all LDS fill levels are back at zero: the carried state is
-//     just the three filter histories.
-#include <hip/hip_runtime.h>
+//     just the three filter histories.#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include "nvx_tables.h"
-#include "nvx_atan2.h"
-#include "nvx_fsm.h"
-#include "nvx_synth.h"
 #include "nvx_kernels.h"
-
-// A single wave owns all LDS it touches; LDS instructions of one wave execute
-// in program order, so cross-lane hand-offs need no s_barrier and no waitcnt --
-// only the compiler must be kept from reordering the accesses.
-#define NVX_WAVE_LDS_FENCE() asm volatile("" ::: "memory")
-
-typedef short nvx_short2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal builtin needs it
+#include "nvx_device.h"
 
 // ------------------------------------------------------------------ LDS map
 // X: four polyphase arrays of 74 double2 (9 history + 64 new + 1 pad; the pad
@@ -94,11 +84,6 @@ struct CascadeLds {
     double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES];
     double  mix[2 * NVX_MIX_N];
 };
-
-// NB: __builtin_bit_cast applied directly to a vector-element expression (v.x)
-// reads element 0 for every component with this compiler; go through a by-value
-// scalar instead.
-__device__ __forceinline__ nvx_short2 as_short2(unsigned w) { return __builtin_bit_cast(nvx_short2, w); }
 
 __device__ __forceinline__ int dpp_swap_pairs(int v)
 {
@@ -492,394 +477,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 }
 
 // ===========================================================================
-// demodulator (receiver/decoder.C), split by what is parallel in time
-// ===========================================================================
-// With g = index of a 900 S/s sample since reset, the reference's counters are
-// pure functions of g (decoder.C:142-255):
-//   delta-phi ring primed at g = 8   -> |corr| value kappa = g - 8 written to
-//                                       ring position kappa mod 567
-//   |corr| ring primed at g = 574    -> one class sum per sample, class
-//                                       c(g) = (g - 574) mod 9, over ring
-//                                       positions c, c+9, ... in ASCENDING
-//                                       POSITION order (not time order)
-//   class sums primed at g = 582     -> arg-max over the 9 sums when
-//                                       (g - 582) mod 9 == 0; at that moment
-//                                       csa[i] = S(g - 8 + i)
-// so delta-phi, |corr|, the class sums S(g) and the arg-max are computed for all
-// samples of a launch in parallel (nvx_demod_front, one workgroup per chain,
-// time-tiled through LDS), and only the two tiny state machines (timing slew
-// limiter, mark/space bit FSM with its five-sample mixed-precision
-// accumulation) run sequentially, one lane per chain (nvx_demod_fsm).
-// Every floating-point sum keeps the reference's operand order.
-//
-// The mark/space decision of a bit depends only on the five consecutive samples
-// of its window (decoder.C:96-125: the sums are zeroed when the window opens),
-// so the decision "if a window ended at sample t" is evaluated for EVERY t in
-// parallel too; the sequential kernel then only picks the one the bit FSM lands
-// on.  Per bit period m the front kernel hands over one 16-bit word:
-//   bits 0..8  decision for a window ending at local sample 9m+k ('B' = 1)
-//   bits 12..15 arg-max of that period's timing evaluation, 15 = none yet
-//
-// Per-slot double state (AoS): last 4 samples {I,Q} (the newest is the
-// discriminator's prevI/prevQ), last 8 delta-phi, last 8 class sums, last 567
-// |corr| values in time order.
-enum { DS_Y3 = 0, DS_DPHI = 8, DS_S = 16, DS_C = 24, DS_COUNT = 24 + 567 };
-// Per-slot int state (SoA over slots)
-enum { DI_SYNCED = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_PHASE, DI_PREV_OFFSET, DI_COUNT };
-static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET &&
-              DI_PHASE == NVX_DI_PHASE, "state layout");
-
-#ifndef NVX_FRONT_THREADS
-#define NVX_FRONT_THREADS 256
-#endif
-#ifndef DTL
-#define DTL 1152                         // time tile: 4 frames of 900 S/s samples (multiple of 9)
-#endif
-#define FRONT_SLIDE ((567 + NVX_FRONT_THREADS - 1) / NVX_FRONT_THREADS)
-#define G_DAB 8
-#define G_CB 574
-#define G_CSA 582
-
-// sample t of the launch, t >= -4: history for negative t
-__device__ __forceinline__ double2 y3_at(const double2 *y3, const double *hist, int t)
-{
-    if (t >= 0) return y3[t];
-    double2 r; r.x = hist[2 * (4 + t)]; r.y = hist[2 * (4 + t) + 1];
-    return r;
-}
-
-__global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_args a)
-{
-    __shared__ double s_dphi[8 + DTL];
-    __shared__ double s_S[8 + DTL];
-    __shared__ double s_C[567 + DTL];
-    __shared__ unsigned char s_D[DTL];
-    const int slot = blockIdx.x, tid = threadIdx.x;
-    if (!a.slot_active[slot]) return;                    // uniform over the block
-
-    double *st = a.dstate + (size_t)slot * NVX_DEMOD_DOUBLES;
-    const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
-    double *dphi_out = a.dphi ? a.dphi + (size_t)slot * a.y3_cap + a.y3_base : nullptr;
-    const double *hist = st + DS_Y3;                     // read in place: only the first 4 samples need it
-    if (tid < 8) { s_dphi[tid] = st[DS_DPHI + tid]; s_S[tid] = st[DS_S + tid]; }
-    for (int i = tid; i < 567; i += NVX_FRONT_THREADS) s_C[i] = st[DS_C + i];
-    __syncthreads();
-
-    for (int ta = 0; ta < a.n3; ta += DTL) {
-        const int tl = min(DTL, a.n3 - ta);
-        const unsigned long long gt = a.g0 + (unsigned long long)ta;     // g of L = 0
-        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
-            const int t = ta + L;
-            // ---- discriminator, decoder.C:48-52
-            const double2 s = y3[t];
-            const double2 p = y3_at(y3, hist, t - 1);
-            const double prodReal = s.x * p.x + s.y * p.y;
-            const double prodImg  = s.y * p.x - s.x * p.y;
-            const double ds = nvx_atan2(prodImg, prodReal);
-            s_dphi[8 + L] = ds;
-            if (dphi_out) dphi_out[t] = ds;
-            // ---- mark/space decision for a window ending here, decoder.C:115-132:
-            // float*float product, double*float product, double sum, accumulate in
-            // double, round to float -- five samples, filter index 0..4
-            float BR = 0.0f, BI = 0.0f, YR = 0.0f, YI = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const double2 w = (i == 4) ? s : ((i == 3) ? p : y3_at(y3, hist, t - 4 + i));
-                const float fR = NVX_BF_R[i], fI = NVX_BF_I[i];
-                const double sampleR = w.x, sampleI = w.y;
-                YR = (float)((double)YR + ((double)((float)sampleR * fR) - sampleI * (double)fI));
-                YI = (float)((double)YI + ((double)((float)sampleR * fI) + sampleI * (double)fR));
-                BR = (float)((double)BR + ((double)((float)sampleR * fR) + sampleI * (double)fI));
-                BI = (float)((double)BI + ((double)((float)(-sampleR) * fI) + sampleI * (double)fR));
-            }
-            const float Brot = BR * BR + BI * BI;
-            const float Yrot = YR * YR + YI * YI;
-            s_D[L] = (Brot > Yrot) ? 1 : 0;
-        }
-        __syncthreads();
-        // ---- transition correlator, decoder.C:157-177: mask[i] * dphi[g-8+i], i ascending
-        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
-            if (gt + L >= G_DAB) {
-                double temp = 0.0;
-#pragma unroll
-                for (int i = 0; i < 9; i++) temp += (double)NVX_CORR_MASK[i] * s_dphi[L + i];
-                s_C[567 + L] = __builtin_fabs(temp);
-            } else {
-                s_C[567 + L] = 0.0;                      // never read; keeps the carried state deterministic
-            }
-        }
-        __syncthreads();
-        // ---- class sum, decoder.C:181-197: ring positions c, c+9, ... ascending.
-        // Position p holds the newest value kappa' <= kappa with kappa' = p (mod 567),
-        // i.e. the value d = (kappa - p) mod 567 samples back.
-        // The order is a rotation of the time order: with d0 = (kappa - c) mod 567 and jw = d0 / 9 the terms are
-        // the samples d0, d0-9, ..., d0-9*jw back (ascending in time, stride 9), then those 558+r, ..., d0+9 back
-        // (r = d0 mod 9) -- two runs of one stride-9 walk through the time-ordered buffer, the second one starting
-        // 567 entries lower.  t_cb = (g of L = 0) - 574 mod 5103 (= 9 * 567) keeps the index arithmetic in 32 bits.
-        const unsigned t_cb = (unsigned)((gt % 5103u + (5103u - G_CB % 5103u)) % 5103u);
-        for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
-            if (gt + L >= G_CB) {
-                const unsigned u = t_cb + (unsigned)L;               // == g - 574 (mod 5103)
-                const unsigned c = u % 9u;
-                const int d0 = (int)((u + 566u - c) % 567u);         // (kappa - c) mod 567, kappa = g - 8
-                const int jw = d0 / 9;
-                const double *run1 = &s_C[567 + L - d0];             // terms j = 0 .. jw
-                const double *run2 = run1 - 567;                     // terms j = jw+1 .. 62
-                double temp = 0.0;
-#pragma unroll
-                for (int j = 0; j < 63; j++) temp += (j <= jw ? run1 : run2)[9 * j];
-                s_S[8 + L] = temp;
-            } else {
-                s_S[8 + L] = 0.0;
-            }
-        }
-        __syncthreads();
-        // ---- one word per bit period: nine window decisions + the arg-max of the
-        // timing evaluation (decoder.C:202-215: csa[i] = S(g-8+i), strict '>' from
-        // -1.0 => first maximum wins), which falls on local sample 9m+6
-        for (int M = tid; M < tl / 9; M += NVX_FRONT_THREADS) {
-            unsigned w = 0;
-#pragma unroll
-            for (int k = 0; k < 9; k++) w |= (unsigned)s_D[9 * M + k] << k;
-            const int L = 9 * M + (G_CSA % 9);
-            unsigned max_index = 15;
-            if (gt + L >= G_CSA) {
-                double temp_max = -1.0;
-                max_index = 0;
-#pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    const double v = s_S[L + i];
-                    if (v > temp_max) { temp_max = v; max_index = i; }
-                }
-            }
-            a.words[(size_t)slot * (a.y3_cap / 9) + (ta / 9 + M)] = (unsigned short)(w | (max_index << 12));
-        }
-        __syncthreads();
-        // ---- slide the histories to the front for the next tile / the next launch
-        double h_d = 0.0, h_s = 0.0, h_c[FRONT_SLIDE];
-        if (tid < 8) { h_d = s_dphi[tl + tid]; h_s = s_S[tl + tid]; }
-#pragma unroll
-        for (int k = 0; k < FRONT_SLIDE; k++) { const int i = tid + NVX_FRONT_THREADS * k; h_c[k] = (i < 567) ? s_C[tl + i] : 0.0; }
-        __syncthreads();
-        if (tid < 8) { s_dphi[tid] = h_d; s_S[tid] = h_s; }
-#pragma unroll
-        for (int k = 0; k < FRONT_SLIDE; k++) { const int i = tid + NVX_FRONT_THREADS * k; if (i < 567) s_C[i] = h_c[k]; }
-        __syncthreads();
-    }
-
-    if (tid < 4 && a.n3 >= 4) { const double2 l = y3[a.n3 - 4 + tid]; st[DS_Y3 + 2 * tid] = l.x; st[DS_Y3 + 2 * tid + 1] = l.y; }
-    if (tid < 8) { st[DS_DPHI + tid] = s_dphi[tid]; st[DS_S + tid] = s_S[tid]; }
-    for (int i = tid; i < 567; i += NVX_FRONT_THREADS) st[DS_C + i] = s_C[i];
-}
-
-// Sequential part: the timing slew limiter (decoder.C:217-249) and the bit FSM
-// (decoder.C:62-137), integers only, one lane per chain.  Both are stated per
-// sample in nvx_fsm.h; the kernel advances a whole bit period at a time with
-// the transition table generated from that statement (29 KB, copied to LDS):
-// the dependent chain per period is the slew rule, one LDS lookup and a few
-// bit operations instead of nine sample steps.
-__global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
-{
-    __shared__ uint32_t s_tab[NVX_FSM_TABLE_ALLOC];
-    {
-        const uint4 *src = (const uint4 *)a.fsm_table;
-        uint4 *dst = (uint4 *)s_tab;
-        for (int i = threadIdx.x; i < NVX_FSM_TABLE_ALLOC / 4; i += 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    const int nc = a.n_slots;
-    if (slot >= nc) return;
-    if (!a.slot_active[slot]) return;
-    int *si = a.state_i;
-#define SI(f) si[(size_t)(f) * nc + slot]
-    nvx_fsm_regs r;
-    r.so = SI(DI_SYNCED) ? SI(DI_SYNC_OFF) : NVX_FSM_UNSYNCED;
-    r.nso = SI(DI_NEXT_SYNC_OFF);
-    r.phase1 = SI(DI_PHASE) + 1;
-    r.prev_offset = SI(DI_PREV_OFFSET);
-
-    // decoded bits are packed ('B' = 1, LSB first) and stored one 32-bit word at a
-    // time: byte stores would sit in front of every prefetched load in the in-order
-    // vmcnt queue
-    unsigned *bits = (unsigned *)(a.bits + (size_t)slot * a.bits_cap);
-    const int cap_words = a.bits_cap / 4;
-    unsigned long long acc = 0;                   // pending bits, LSB first
-    int nacc = 0, nwords = 0;                     // bits pending in acc (< 64), words already stored
-    const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
-    // one row of 16-bit words per chain: eight bit periods per 16-byte load, requested one group ahead
-    const uint4 *words = (const uint4 *)(a.words + (size_t)slot * (a.y3_cap / 9));
-    uint4 wnext = words[0];
-
-    for (int m0 = 0; m0 < periods; m0 += 8) {     // periods is a multiple of 32
-        const uint4 wv = wnext;
-        if (m0 + 8 < periods) wnext = words[m0 / 8 + 1];
-        const unsigned wcur[8] = { wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16,
-                                   wv.z & 0xffffu, wv.z >> 16, wv.w & 0xffffu, wv.w >> 16 };
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int n;
-            const unsigned b = nvx_fsm_period(s_tab, wcur[i], &r, &n);
-            acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
-            nacc += n;
-        }
-        // at most 10 bits per 8 periods: one store check per group
-        if (nacc >= 32) {
-            if (nwords < cap_words) bits[nwords] = (unsigned)acc;
-            nwords++; acc >>= 32; nacc -= 32;
-        }
-    }
-    if (nacc > 0 && nwords < cap_words) bits[nwords] = (unsigned)acc;
-
-    a.nbits[slot] = nwords * 32 + nacc;
-    const int synced = r.so != NVX_FSM_UNSYNCED;
-    SI(DI_SYNCED) = synced; SI(DI_SYNC_OFF) = synced ? r.so : 0; SI(DI_NEXT_SYNC_OFF) = r.nso;
-    SI(DI_PHASE) = r.phase1 - 1; SI(DI_PREV_OFFSET) = r.prev_offset;
-#undef SI
-}
-
-// ===========================================================================
-// wideband front-end: 8-channel polyphase channeliser (build-owned, integer)
-// ===========================================================================
-// One 2.016 MS/s stream -> eight 252 kS/s sub-bands centred at k * 252 kHz, each
-// ready for the 252 kS/s cascade (two NAVTEX chains per sub-band).  Definition
-// (the test suite holds an independent scalar restatement of exactly these steps):
-//   u[p]  = (sum_{j = p mod 8} h[47-j] * x[8m-40+j] + 16) >> 5
-//   Y[k]  = radix-2 DIT DFT_8(u), 45-degree twiddles = 23170 / 2^15 with floor shifts
-//   out_k = clamp16((Y[k] + 4096) >> 13)
-// Mapping: one wave per span of one wideband stream; a chunk = 64 output instants =
-// 512 raw samples (2 KiB in, 8 x 256 B out).  The 48-sample window of lane m is
-// LDS words 8m .. 8m+47 (twelve ds_read_b128); the branch sums use v_dot2_i32_i16
-// with (h, 0) / (0, h) selector constants, so no sign extension is needed.
-#define NVX_PFB_TABLE static constexpr
-#include "nvx_pfb_taps.h"
-
-__device__ __forceinline__ int mulc45(int t) { return (int)(((long long)t * NVX_PFB_C45) >> 15); }
-__device__ __forceinline__ unsigned pack_clamp16(int re, int im)
-{
-    re = (re + 4096) >> 13; im = (im + 4096) >> 13;
-    re = re > 32767 ? 32767 : (re < -32768 ? -32768 : re);
-    im = im > 32767 ? 32767 : (im < -32768 ? -32768 : im);
-    return ((unsigned)re & 0xffffu) | ((unsigned)im << 16);
-}
-
-__global__ __launch_bounds__(64) void nvx_channelise(nvx_channelise_args a)
-{
-    __shared__ __attribute__((aligned(16))) unsigned win[40 + 512];
-    const int lane = threadIdx.x;
-    const int wide = blockIdx.y;
-    const size_t n_chunks = a.n_out / 64;
-    const size_t c0 = (size_t)blockIdx.x * a.chunks_per_block;
-    if (c0 >= n_chunks) return;
-    const size_t c1 = min(n_chunks, c0 + (size_t)a.chunks_per_block);
-    const unsigned *raw = a.raw + (size_t)wide * a.pitch_raw + a.first_sample;
-
-    // history: the 40 raw samples in front of this span
-    if (lane < 40) {
-        unsigned v = 0;
-        if (c0 > 0) v = raw[c0 * 512 - 40 + lane];
-        else if (a.hist_in) v = a.hist_in[(size_t)wide * 40 + lane];
-        win[lane] = v;
-    }
-    for (size_t c = c0; c < c1; c++) {
-        const u32x4 *src = (const u32x4 *)(raw + c * 512) + lane;
-        const u32x4 v0 = __builtin_nontemporal_load(src), v1 = __builtin_nontemporal_load(src + 64);
-        *(u32x4 *)&win[40 + 4 * lane] = v0;
-        *(u32x4 *)&win[40 + 256 + 4 * lane] = v1;
-        NVX_WAVE_LDS_FENCE();
-
-        int ur[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ui[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int r = 0; r < 12; r++) {
-            const u32x4 w = *(const u32x4 *)&win[8 * lane + 4 * r];
-            const unsigned ww[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int j = 4 * r + e;
-                const int h = NVX_PFB_H[47 - j];
-                const nvx_short2 hI = { (short)h, 0 }, hQ = { 0, (short)h };
-                ur[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), hI, ur[j & 7], false);
-                ui[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), hQ, ui[j & 7], false);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 8; p++) { ur[p] = (ur[p] + 16) >> 5; ui[p] = (ui[p] + 16) >> 5; }
-
-        int ar[8], ai[8], br[8], bi[8];
-        ar[0] = ur[0] + ur[4]; ai[0] = ui[0] + ui[4];  ar[1] = ur[0] - ur[4]; ai[1] = ui[0] - ui[4];
-        ar[2] = ur[2] + ur[6]; ai[2] = ui[2] + ui[6];  ar[3] = ur[2] - ur[6]; ai[3] = ui[2] - ui[6];
-        ar[4] = ur[1] + ur[5]; ai[4] = ui[1] + ui[5];  ar[5] = ur[1] - ur[5]; ai[5] = ui[1] - ui[5];
-        ar[6] = ur[3] + ur[7]; ai[6] = ui[3] + ui[7];  ar[7] = ur[3] - ur[7]; ai[7] = ui[3] - ui[7];
-        br[0] = ar[0] + ar[2]; bi[0] = ai[0] + ai[2];  br[2] = ar[0] - ar[2]; bi[2] = ai[0] - ai[2];
-        br[1] = ar[1] + ai[3]; bi[1] = ai[1] - ar[3];  br[3] = ar[1] - ai[3]; bi[3] = ai[1] + ar[3];
-        br[4] = ar[4] + ar[6]; bi[4] = ai[4] + ai[6];  br[6] = ar[4] - ar[6]; bi[6] = ai[4] - ai[6];
-        br[5] = ar[5] + ai[7]; bi[5] = ai[5] - ar[7];  br[7] = ar[5] - ai[7]; bi[7] = ai[5] + ar[7];
-        const int w1r = mulc45(br[5] + bi[5]), w1i = mulc45(bi[5] - br[5]);
-        const int w3r = mulc45(bi[7] - br[7]), w3i = mulc45(-br[7] - bi[7]);
-        unsigned y[8];
-        y[0] = pack_clamp16(br[0] + br[4], bi[0] + bi[4]);  y[4] = pack_clamp16(br[0] - br[4], bi[0] - bi[4]);
-        y[1] = pack_clamp16(br[1] + w1r, bi[1] + w1i);      y[5] = pack_clamp16(br[1] - w1r, bi[1] - w1i);
-        y[2] = pack_clamp16(br[2] + bi[6], bi[2] - br[6]);  y[6] = pack_clamp16(br[2] - bi[6], bi[2] + br[6]);
-        y[3] = pack_clamp16(br[3] + w3r, bi[3] + w3i);      y[7] = pack_clamp16(br[3] - w3r, bi[3] - w3i);
-
-        unsigned *out = a.sub + (size_t)wide * 8 * a.pitch_sub + a.sub_first + c * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < 8; k++) out[(size_t)k * a.pitch_sub] = y[k];
-
-        // slide: the newest 40 raw samples become the history of the next chunk
-        NVX_WAVE_LDS_FENCE();
-        unsigned t = 0;
-        if (lane < 40) t = win[512 + lane];
-        NVX_WAVE_LDS_FENCE();
-        if (lane < 40) win[lane] = t;
-        NVX_WAVE_LDS_FENCE();
-    }
-    if (c1 == n_chunks && a.hist_out && lane < 40) a.hist_out[(size_t)wide * 40 + lane] = win[lane];
-}
-
-// ===========================================================================
-// synthetic source
-// ===========================================================================
-__global__ __launch_bounds__(256) void nvx_synth_kernel(nvx_synth_args a)
-{
-    const int stream = blockIdx.y;
-    const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;    // 4 samples per thread
-    const size_t n0 = quad * 4;
-    if (n0 >= a.n) return;
-    const nvx_synth_desc *d = a.desc + stream;
-    int32_t I[4] = { 0, 0, 0, 0 }, Q[4] = { 0, 0, 0, 0 };
-    const int nc = d->n_carriers;
-    for (int c = 0; c < nc; c++) {                    // carrier-major: the 4-sample arrays keep static indices
-        const uint64_t g = (uint64_t)n0 + d->bit_offset[c];
-        size_t b = (size_t)(g / a.spb);
-        uint32_t r = (uint32_t)(g - (uint64_t)b * a.spb);
-        const nvx_period *pool = a.pool + d->pool_off[c];
-        nvx_period p = pool[b];
-        uint32_t ph = p.phase + r * p.inc;
-        const int32_t amp = d->amp[c];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            nvx_synth_tone(ph, amp, &I[k], &Q[k]);
-            ph += p.inc;
-            if (++r == a.spb) { r = 0; b++; p = pool[b]; ph = p.phase; }     // next bit period
-        }
-    }
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (d->noise_amp > 0) nvx_synth_noise(d->seed, (uint64_t)(n0 + k), d->noise_amp, &I[k], &Q[k]);
-        w[k] = nvx_synth_pack(I[k], Q[k]);
-    }
-    uint32_t *out = a.out + (size_t)stream * a.pitch + n0;
-    if (n0 + 4 <= a.n) {
-        *(uint4 *)out = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-        for (size_t k = 0; n0 + k < a.n; k++) out[k] = w[k];
-    }
-}
-
-// ===========================================================================
-// launchers (C linkage, called from the host runtime)
+// launcher (C linkage, called from the host runtime)
 // ===========================================================================
 // tuning switches for A/B runs (defaults are the shipped configuration)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -929,34 +527,3 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
     return nch == 1 ? NVX_CASE(false, 1) : NVX_CASE(false, 2);
 #undef NVX_CASE
 }
-
-extern "C" hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStream_t s)
-{
-    const size_t n_chunks = a->n_out / 64;
-    const unsigned bx = (unsigned)((n_chunks + a->chunks_per_block - 1) / a->chunks_per_block);
-    hipLaunchKernelGGL(nvx_channelise, dim3(bx, (unsigned)a->n_wide), dim3(64), 0, s, *a);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s)
-{
-    hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(NVX_FRONT_THREADS), 0, s, *a);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t nvx_launch_demod_fsm(const nvx_demod_args *a, hipStream_t s)
-{
-    hipLaunchKernelGGL(nvx_demod_fsm, dim3((unsigned)((a->n_slots + 63) / 64)), dim3(64), 0, s, *a);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s)
-{
-    const size_t quads = (a->n + 3) / 4;
-    dim3 grid((unsigned)((quads + 255) / 256), (unsigned)n_streams), block(256);
-    hipLaunchKernelGGL(nvx_synth_kernel, grid, block, 0, s, *a);
-    return hipGetLastError();
-}
-
-// host-callable copy of the device atan2, for tests (tests/test_atan2.py)
-extern "C" __attribute__((visibility("default"))) double nvx_atan2_host(double y, double x) { return nvx_atan2(y, x); }

@@ -15,15 +15,17 @@ pytestmark = pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not avai
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
-    out = tmp_path_factory.mktemp("isa") / "k.s"
+    tmp = tmp_path_factory.mktemp("isa")
     csrc = ROOT / "navtex_amd" / "csrc"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{csrc}",
-                    "--cuda-device-only", "-S", str(csrc / "nvx_kernels.hip"), "-o", str(out)], check=True, capture_output=True)
-    text = out.read_text()
-    kernels = {}
-    for m in re.finditer(r"^(_Z\w+):.*?s_endpgm", text, flags=re.S | re.M):
-        kernels[m.group(1)] = m.group(0)
-    meta = text[text.index("amdhsa.kernels"):] if "amdhsa.kernels" in text else ""
+    kernels, meta = {}, ""
+    for src in sorted(csrc.glob("*.hip")):                # every device translation unit of the product
+        out = tmp / (src.stem + ".s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{csrc}",
+                        "--cuda-device-only", "-S", str(src), "-o", str(out)], check=True, capture_output=True)
+        text = out.read_text()
+        for m in re.finditer(r"^(_Z\w+|nvx_\w+):.*?s_endpgm", text, flags=re.S | re.M):
+            kernels[m.group(1)] = m.group(0)
+        meta += text[text.index("amdhsa.kernels"):] if "amdhsa.kernels" in text else ""
     return kernels, meta
 
 
@@ -49,4 +51,4 @@ def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
 def test_no_kernel_spills(isa):
     _, meta = isa
     sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", meta)]
-    assert sizes and all(s == 0 for s in sizes), sizes
+    assert len(sizes) >= 16 + 4 and all(s == 0 for s in sizes), sizes      # 16 cascade instantiations + demod x2, channeliser, generator
