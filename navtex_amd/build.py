@@ -53,25 +53,29 @@ def _stale(out: Path, deps) -> bool:
 
 
 def build_lib(force: bool = False) -> Path:
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
     OBJ.mkdir(exist_ok=True)
     headers = list(CSRC.glob("*.h")) + [ROOT / "include" / "navtex_amd.h", Path(__file__)]
-    objs = []
+    objs, jobs = [], []
     for src in C_SOURCES:
         o = OBJ / (src + ".o")
         if force or _stale(o, [CSRC / src] + headers):
-            _run([hipcc, "-x", "c", "-std=gnu11", "-Wall", "-Wextra", *COMMON, "-c", CSRC / src, "-o", o])
+            jobs.append([hipcc, "-x", "c", "-std=gnu11", "-Wall", "-Wextra", *COMMON, "-c", CSRC / src, "-o", o])
         objs.append(o)
     for src in HIP_SOURCES:
         o = OBJ / (src + ".o")
         if force or _stale(o, [CSRC / src] + headers):
-            _run([hipcc, f"--offload-arch={ARCH}", "-std=c++17", *COMMON, "-c", CSRC / src, "-o", o])
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-std=c++17", *COMMON, "-c", CSRC / src, "-o", o])
         objs.append(o)
     for src in CXX_SOURCES:
         o = OBJ / (src + ".o")
         if force or _stale(o, [CSRC / src] + headers):
-            _run([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-std=c++17", "-Wall", "-Wno-unused-value", "-Wno-unused-result", *COMMON, "-c", CSRC / src, "-o", o])
+            jobs.append([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-std=c++17", "-Wall", "-Wno-unused-value", "-Wno-unused-result", *COMMON, "-c", CSRC / src, "-o", o])
         objs.append(o)
+    # the translation units are independent: compile them side by side (the cascade's 16 instantiations dominate)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(_run, jobs))
     if force or _stale(LIB, objs):
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lpthread", "-ldl"])
     return LIB
