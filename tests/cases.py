@@ -199,3 +199,19 @@ def make_bits(nv, spec) -> str:
         # each variant followed by enough traffic to see whether byte reception started
         return "".join(p + msg + "B" * 1200 for p in parts)
     raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------
+# WAV boundary cases (receiver/wav.c as receiver/capt_sched.c:87-101,516 uses it): frames of int16 I,Q
+# --------------------------------------------------------------------------
+WAV_CASES = {
+    "capture_252k": {"frames": 5000, "rate": 252000, "seed": 11},     # the reference's own capture format
+    "one_frame": {"frames": 1, "rate": 252000, "seed": 12},
+    "empty": {"frames": 0, "rate": 252000, "seed": 13},
+    "raw_rate": {"frames": 4097, "rate": 2016000, "seed": 14},       # the build's wideband recordings
+}
+
+
+def make_wav_frames(spec) -> np.ndarray:
+    rng = np.random.default_rng(spec["seed"])
+    return rng.integers(-32768, 32768, size=(spec["frames"], 2), dtype=np.int16)

@@ -54,18 +54,24 @@ def test_encoder_skips_untransmittable(nv):
     assert nv.sitor_encode("abc", 1) == nv.sitor_encode("ABC", 1)
 
 
-def test_wav_header_is_canonical_44_bytes(nv, tmp_path):
-    """Same header receiver/wav.c writes for the reference's capture format
-    (2 ch, 16 bit, 252 kHz: capt_sched.c:91-95)."""
-    iq = np.arange(2000, dtype=np.int16).reshape(-1, 2)
+@pytest.mark.parametrize("name", sorted(GOLD["wav"]))
+def test_wav_file_matches_what_the_reference_writes(nv, tmp_path, name):
+    """nvx_wav_write against receiver/wav.c COMPILED (oracle/_ref/ref_wav, golden "wav"): the file is the reference's
+    44 header bytes followed by the frames, byte for byte -- for the reference's capture format (2 ch, 16 bit, 252 kHz:
+    capt_sched.c:91-95), one frame, no frames, and the 2.016 MS/s recordings; and the reference's own wav_read
+    (wav.c:494-528) got the same frames back from the product's file when the golden was made."""
+    rec = GOLD["wav"][name]
+    frames = cases.make_wav_frames(rec["spec"])
     path = str(tmp_path / "cap.wav")
-    nv.wav_write(path, iq, 252000)
+    nv.wav_write(path, frames, rec["spec"]["rate"])
     raw = Path(path).read_bytes()
-    want = (b"RIFF" + struct.pack("<I", 36 + iq.nbytes) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 252000, 1008000, 4, 16)
-            + b"data" + struct.pack("<I", iq.nbytes))
-    assert raw[:44] == want and raw[44:] == iq.tobytes()
+    assert raw[:44].hex() == rec["header_hex"] and len(raw) == rec["file_bytes"]
+    assert hashlib.sha256(raw[44:]).hexdigest() == rec["data_sha256"] and raw[44:] == frames.tobytes()
     back, rate = nv.wav_read(path)
-    assert rate == 252000 and np.array_equal(back, iq)
+    assert rate == rec["spec"]["rate"] and np.array_equal(back.reshape(-1, 2), frames)
+    rr = rec["reference_reads_product_file"]
+    assert (rr["format"], rr["channels"], rr["rate"], rr["sample_size"], rr["length"]) == (1, 2, rec["spec"]["rate"], 2, rec["spec"]["frames"])
+    assert rr["data_sha256"] == rec["data_sha256"]
 
 
 def test_wav_reader_skips_unknown_chunks(nv, tmp_path):

@@ -75,3 +75,20 @@ def test_decoder_random_inputs(oracle):
     r = ob.run_ref("dec", np.ascontiguousarray(y3).tobytes())
     bits, _ = oracle.decode(y3)
     assert bits == r["bits518"].decode() and len(bits) > 500
+
+
+@pytest.mark.skipif(not ob.have_ref_wav(), reason="compiled reference wav.c (oracle/_ref/ref_wav) not present")
+@pytest.mark.parametrize("seed,n,rate", [(1, 3, 252000), (2, 70001, 252000), (3, 12345, 2016000), (4, 0, 252000)])
+def test_wav_boundary_both_directions_live(nv, tmp_path, seed, n, rate):
+    """reference wav_write -> product nvx_wav_read, and product nvx_wav_write -> reference wav_read
+    (receiver/wav.c:469-528), on fresh random frames."""
+    frames = np.random.default_rng(seed).integers(-32768, 32768, size=(n, 2), dtype=np.int16)
+    blob = ob.ref_wav_write(frames, rate)
+    f = tmp_path / "ref.wav"; f.write_bytes(blob)
+    back, got_rate = nv.wav_read(str(f))
+    assert got_rate == rate and np.array_equal(back.reshape(-1, 2), frames)
+    p = str(tmp_path / "product.wav")
+    nv.wav_write(p, frames, rate)
+    assert open(p, "rb").read() == blob, "product and reference files differ"
+    meta, data = ob.ref_wav_read(p)
+    assert meta == (1, 2, rate, 2, n) and data == frames.tobytes()
