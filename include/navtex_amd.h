@@ -114,6 +114,11 @@ NVX_API void nvx_capture_callback(short *xi, short *xq, void *params, unsigned i
 NVX_API int  nvx_capture_stop(nvx_capture *c);
 /* complex samples offered by the producer / dropped on overrun / handed to the GPU pipeline */
 NVX_API void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed);
+/* Health of the consumer while it runs: returns the error that stopped it (NVX_OK while it is alive; a HIP failure is
+ * the only thing that stops it early) and, optionally, how often it found the handle's staging full because ANOTHER
+ * stream of the same handle had stalled -- that is back-pressure: the consumer keeps the samples in the ring, retries
+ * every 50 ms, and the ring's overrun accounting (dropped) counts what is lost meanwhile.                           */
+NVX_API int  nvx_capture_error(nvx_capture *c, uint64_t *full_waits);
 /* debug recording (the reference's debug_mode, capt_sched.c:87-101 PrepWav/EndWav and :516):
  * every span the consumer hands to the pipeline is also appended to a 2-channel 16-bit WAV
  * at the handle's input rate.  filename NULL stops and closes; nvx_capture_stop closes too. */
@@ -168,7 +173,8 @@ NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const 
 /* wait for all launched work, deliver bits/messages                          */
 NVX_API int nvx_flush(nvx_handle *h);
 /* copy out and consume decoded bits ('B'/'Y') of one chain; returns count.
- * The receiver runs unattended for weeks (receiver/main.c), so the library keeps
+ * The receiver runs unattended for weeks (main(), receiver/capt_sched.c:558, and its
+ * endless capture loop :618-621), so the library keeps
  * only the most recent cfg.bit_history bits per chain (up to twice that between
  * trims): a reader further behind resumes at the oldest bit still held.  The
  * character layer sees every bit regardless.                                 */
@@ -180,8 +186,10 @@ NVX_API size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, si
  * complex samples; stream s, frame f starts at d_iq + 4*(s*pitch + f*FRAME).
  * Processes `n_frames` frames starting at frame `first_frame` of every stream
  * on `hip_stream` (a hipStream_t; NULL = the handle's own stream), carrying
- * state from the previous call.  Asynchronous; bits stay on the device until
- * nvx_fetch_bits.                                                            */
+ * state from the previous call.  Successive calls may name different streams:
+ * the library orders a launch behind its predecessor (the carried state makes
+ * launches of one handle sequential by nature).  Asynchronous; bits stay on
+ * the device until nvx_fetch_bits.                                           */
 NVX_API int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch_samples,
                                  size_t first_frame, int n_frames, void *hip_stream);
 /* synchronise, run the character layer (if enabled) on the new bits          */

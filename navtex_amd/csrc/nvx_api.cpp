@@ -62,6 +62,7 @@ static void free_handle(nvx_handle *h)
 {
     if (!h) return;
     hipSetDevice(h->cfg.device);
+    if (h->launch_done_valid) hipEventSynchronize(h->launch_done);      // the last launch may sit on a caller's stream
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->stream2) hipStreamSynchronize(h->stream2);
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
@@ -74,6 +75,7 @@ static void free_handle(nvx_handle *h)
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate[0]); hipFree(h->d_cstate[1]); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
+    if (h->launch_done) hipEventDestroy(h->launch_done);
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
@@ -150,6 +152,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipEventCreateWithFlags(&h->demod_done[i], hipEventDisableTiming));
     }
     CR_TRY(hipEventCreateWithFlags(&h->fsm_done, hipEventDisableTiming));
+    CR_TRY(hipEventCreateWithFlags(&h->launch_done, hipEventDisableTiming));
     std::vector<uint8_t> active(h->n_slots);
     for (int i = 0; i < h->n_slots; i++) active[i] = h->slots[i].active;
     CR_TRY(hipMalloc(&h->d_masks, h->n_streams));
@@ -206,8 +209,10 @@ extern "C" int nvx_reset(nvx_handle *h)
     if (!h) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));   // launches on a caller's stream included
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream2));
+    h->launch_done_valid = false;
     for (auto &r : h->res) r.pending = false;
     h->collected = h->launched;
     h->g0 = 0;
@@ -242,6 +247,9 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
     Result &r = h->res[h->launched % RESULT_SLOTS];
     if (r.pending) { int rc = nvx_collect_locked(h); if (rc != NVX_OK) return rc; }
+
+    // a launch on another stream than its predecessor: order it behind the predecessor's last operation
+    if (h->launch_done_valid && st != h->last_launch_stream) HIP_TRY(hipStreamWaitEvent(st, h->launch_done, 0));
 
     const int wb = (int)(h->wide_launches & 1);
     // Measured (profiles/r01, DESIGN.md tuning log): letting the channeliser of launch k+1 run beside the
@@ -318,6 +326,8 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipEventRecord(r.done, s2));
+    HIP_TRY(hipEventRecord(h->launch_done, s2));                    // s2 is st, or has waited for st's last operation
+    h->launch_done_valid = true; h->last_launch_stream = st;
     r.pending = true;
     h->launched++;
     h->last_n3 = da.n3;
@@ -467,6 +477,7 @@ extern "C" int nvx_enable_debug(nvx_handle *h, int enabled)
     if (!h) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (enabled && !h->d_dphi) HIP_TRY(hipMalloc(&h->d_dphi, (size_t)h->n_slots * h->y3_cap * sizeof(double)));
     if (!enabled && h->d_dphi) { hipFree(h->d_dphi); h->d_dphi = nullptr; }

@@ -10,7 +10,7 @@ struct nvx_capture {
     std::vector<int16_t> ring;                  // interleaved I,Q (capt_sched.c:443: shorts)
     size_t cap = 0;                             // complex samples
     std::atomic<uint64_t> head{ 0 }, tail{ 0 }; // samples ever written / ever read
-    std::atomic<uint64_t> received{ 0 }, dropped{ 0 }, consumed{ 0 };
+    std::atomic<uint64_t> received{ 0 }, dropped{ 0 }, consumed{ 0 }, full_waits{ 0 };
     std::mutex prod_mu;                         // callback re-entrancy (capt_sched.c:111)
     std::mutex cv_mu; std::condition_variable cv;
     std::atomic<bool> stop{ false }, paused{ false };
@@ -30,12 +30,19 @@ static void capture_consumer(nvx_capture *c)
         }
         if (c->paused.load() && !c->stop.load()) continue;
         uint64_t t = c->tail.load(), hd = c->head.load();
-        while (t != hd) {                                                // contiguous spans, wrap split as capt_sched.c:494-503
+        bool backoff = false;
+        while (t != hd && !(c->paused.load() && !c->stop.load())) {      // contiguous spans, wrap split as capt_sched.c:494-503
             size_t at = (size_t)(t % c->cap);
             size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
-            int rc = nvx_push_iq(c->h, c->stream, c->ring.data() + 2 * at, n);
-            if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }
-            {
+            size_t took = 0;
+            int rc = nvx_push_iq_partial(c->h, c->stream, c->ring.data() + 2 * at, n, &took);
+            // Another stream of the handle is a whole staging set behind (its radio stalled): back-pressure, not an
+            // error.  Keep what was not taken in the ring (its overrun accounting counts any loss) and retry after the
+            // poll interval; while stopping there is nobody left to catch up, so the rest is given up.
+            if (rc == NVX_ERR_FULL) { c->full_waits.fetch_add(1); backoff = true; }
+            else if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }      // hard error (HIP): give up, report
+            n = took;
+            if (n) {
                 std::lock_guard<std::mutex> lk(c->rec_mu);
                 if (c->rec && nvx_wav_write(c->rec, c->ring.data() + 2 * at, n) != n) {     // disk full etc.: stop recording, keep decoding
                     nvx_wav_close(c->rec); c->rec = nullptr;
@@ -44,6 +51,12 @@ static void capture_consumer(nvx_capture *c)
             t += n;
             c->tail.store(t);
             c->consumed.fetch_add(n);
+            if (backoff) break;
+        }
+        if (backoff) {
+            if (c->stop.load()) { c->error.store(NVX_ERR_FULL); return; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            continue;
         }
         if (c->stop.load() && c->head.load() == c->tail.load()) return;
     }
@@ -113,6 +126,13 @@ extern "C" void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *
     if (received) *received = c->received.load();
     if (dropped) *dropped = c->dropped.load();
     if (consumed) *consumed = c->consumed.load();
+}
+
+extern "C" int nvx_capture_error(nvx_capture *c, uint64_t *full_waits)
+{
+    if (!c) return NVX_ERR_ARG;
+    if (full_waits) *full_waits = c->full_waits.load();
+    return c->error.load();
 }
 
 extern "C" int nvx_capture_stop(nvx_capture *c)

@@ -37,9 +37,15 @@
 //   * stage 0 sums 8 raw samples with SDWA half-word pair adds (sign-extend +
 //     add of two samples in one op) and one DPP lane-pair exchange; each lane
 //     converts one component to fp64 and writes it to the LDS window;
-//   * the 252 kS/s window is kept polyphase-split (4 arrays of {I,Q} doubles)
-//     so that lane k's tap reads are consecutive 16-byte words: every
-//     ds_read_b128 / ds_write_b64 of FIR1 / stage 0 is bank-conflict free;
+//   * FIR1 is split by COMPONENT: lane = (output pair k, component), each lane
+//     accumulates outputs 2k and 2k+1 of its own component.  The two outputs
+//     share 37 of their 41 input samples, so a lane reads 41 x 8 bytes from LDS
+//     for two outputs instead of 2 x 37 x 16 for one complex output each: 45 % of
+//     the LDS bytes per output (the 252 kS/s kernels were LDS-bandwidth bound:
+//     profiles/r02/a0_*).  The window is polyphase-split by 8 ({I,Q} doubles) so
+//     that the 64 lanes of every read touch 512 consecutive bytes: all
+//     ds_read_b64 / ds_write_b64 / ds_write_b128 of FIR1 / stage 0 / the input
+//     conversion are bank-conflict free;
 //   * FIR2 and FIR3 run on batches of pending outputs sized to fill the wave
 //     (struct Geo below); a frame of 32 bit periods = 315 passes is a whole
 //     number of every batch, after which every decimation counter, the mixer
@@ -53,13 +59,18 @@
 #include "nvx_device.h"
 
 // ------------------------------------------------------------------ LDS map
-// X: four polyphase arrays of 74 double2 (9 history + 64 new + 1 pad; the pad
-//    makes the array stride = 8 banks mod 32 so the stage-0 writes spread)
+// X: eight polyphase arrays P_r[e] of 37 double2: entry e of phase r holds sample 8*(e - 5) + r of the pass
+//    (5 history entries: a lane reaches back 33 samples; 32 new ones).  37 is odd and = 5 mod 8, which spreads
+//    both write patterns (stage 0: ds_write_b64, lane pairs walk the phases; 252 kS/s input: ds_write_b128,
+//    lane parity picks the phase quartet) over all banks.
 // U[c]:  mixer output buffer, 46 history + pending (batch + up to 63)
 // Y2[c]: FIR2 output buffer, 70 history + pending (batch + one FIR2 run - 1)
-// MIX:   9 + 9 doubles
-#define XS 74
-#define X_ENTRIES (4 * XS)
+// MIX:   2 signs x 2 periods x 9 x (cos, -+sin): index mixbase + (o mod 9) + 1 <= 17 needs no wrap, and the lane's
+//        sign of the cross product (step 4) is part of its table address
+#define XPH 8
+#define XH 5
+#define XS 37
+#define X_ENTRIES (XPH * XS)
 #ifndef NVX_Y2_RUN
 #define NVX_Y2_RUN 160                    /* single-chain kernel: FIR2 outputs per FIR3 run, 160 (16 outputs) or 80 */
 #endif
@@ -82,13 +93,67 @@ struct CascadeLds {
     double2 X[X_ENTRIES];
     double2 U[NCH][GeoSizes<NCH>::U_ENTRIES];
     double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES];
-    double  mix[2 * NVX_MIX_N];
+    double2 mix[2][2 * NVX_MIX_N];      // [sign of the cross term][two periods of (cos, -+sin)]
 };
 
 __device__ __forceinline__ int dpp_swap_pairs(int v)
 {
     // quad_perm [1,0,3,2]: every lane reads its lane^1 neighbour
     return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+}
+
+// FIR1 window: s_j = x[8*half + 7 - j] is component comp of X[r * XS + XH + half + fl] with 7 - j = 8 * fl + r;
+// offset in doubles from the lane's base pointer
+#ifndef NVX_F1_GROUP
+#define NVX_F1_GROUP 4                    /* LDS reads per wait */
+#endif
+#ifndef NVX_F1_AHEAD
+#define NVX_F1_AHEAD 3                    /* groups in flight ahead of the arithmetic */
+#endif
+#define NVX_F23_AHEAD 12
+// timing probes (wrong results on purpose; never shipped): 1 = FIR1 without its LDS reads, 2 = FIR1 without its fp64
+// arithmetic, 3 = no FIR2 / FIR3
+#ifndef NVX_PROBE
+#define NVX_PROBE 0
+#endif
+// NVX_PROBE == 9: diagnostic build with s_memtime stamps at the phase boundaries of a pass (the stamps wait for the
+// LDS queue, so the build runs slower; it shows where a wave's time goes, nothing else).  Prints per-wave totals.
+#if NVX_PROBE == 9
+#define NVX_STAMP(k) do { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define NVX_STAMP(k) do { } while (0)
+#endif
+#if NVX_PROBE == 1 || NVX_PROBE == 7
+#define NVX_PROBE_READ(expr, j) ((double)(lane + (j)))
+#else
+#define NVX_PROBE_READ(expr, j) (expr)
+#endif                  /* FIR2 / FIR3: taps read ahead */
+__device__ __forceinline__ constexpr int f1_offset(int j)
+{
+    const int t = 7 - j, r = t & 7, fl = (t - r) / 8;
+    return 2 * (r * XS + fl);
+}
+
+// The FIR1 taps live in VGPRs for the whole kernel (22 distinct values = 44 registers).  As literals they cost two
+// s_mov_b32 per tap per pass (74 scalar instructions beside 154 fp64 ones: the 252 kS/s kernels are bound by the
+// instruction issue slots of their few resident waves, profiles/r02) and their SGPR pressure makes the compiler
+// park loop invariants in VGPR lanes (v_readlane / v_writelane in the pass loop).
+template <int N> struct TapIndex {
+    int first[N];
+    constexpr TapIndex(const double (&h)[N]) : first{}
+    {
+        for (int i = 0; i < N; i++) {
+            int f = i;
+            for (int k = 0; k < i; k++) if (h[k] == h[i]) { f = k; break; }
+            first[i] = f;
+        }
+    }
+};
+static constexpr TapIndex<NVX_T1> NVX_H1_FIRST(NVX_H1);
+
+__device__ __forceinline__ double dpp_swap_pairs_f64(double v)
+{
+    return __hiloint2double(dpp_swap_pairs(__double2hiint(v)), dpp_swap_pairs(__double2loint(v)));
 }
 
 // stage 0 for one 1-KiB load: lane l holds raw samples 4l..4l+3 of the KiB;
@@ -198,29 +263,39 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
     __shared__ CascadeLds<NCH> lds;
     const int lane = threadIdx.x;
 
-    if (lane < NVX_MIX_N) {
+    if (lane < 4 * NVX_MIX_N) {
         // constant-index selects keep the tables out of scratch
+        const int j9 = lane % NVX_MIX_N;
         double cr = 0.0, ci = 0.0;
 #pragma unroll
-        for (int j = 0; j < NVX_MIX_N; j++) if (lane == j) { cr = NVX_MIX_CR[j]; ci = NVX_MIX_CI[j]; }
-        lds.mix[lane] = cr; lds.mix[NVX_MIX_N + lane] = ci;
+        for (int j = 0; j < NVX_MIX_N; j++) if (j9 == j) { cr = NVX_MIX_CR[j]; ci = NVX_MIX_CI[j]; }
+        lds.mix[0][lane % (2 * NVX_MIX_N)] = double2{ cr, ci };      // both copies are written by two lanes each: same value
+        lds.mix[1][lane % (2 * NVX_MIX_N)] = double2{ cr, -ci };
     }
 
     // ------------------------------------------------------ lane constants
     const size_t pass_words = RAW ? 2048 : 256;    // 32-bit IQ words per pass
     const size_t pass_stride = pass_words / 4;     // in 16-byte units
     constexpr int NPF = RAW ? 8 : 1;
-    // stage-0 write slot of this lane (RAW): output m = 32j + (lane>>1):
-    // phase r = m & 3, index k' = m >> 2 = 8j + (lane>>3), component = lane & 1
-    double *xw = (double *)&lds.X[((lane >> 1) & 3) * XS + 9 + (lane >> 3)] + (lane & 1);
-    const bool odd = lane & 1;
-    // FIR1 read base of this lane: X[r*XS + 9 + lane - q]
-    const double2 *xr = &lds.X[9 + lane];
-    // FIR2 / FIR3: lane = 2*output + component
+    // lane = 2 * (pair / output index) + component, in stage 0, FIR1, the mixer, FIR2 and FIR3 alike
     const int half = lane >> 1, comp = lane & 1;
-    const int lane_mod9 = lane % 9;
+    const bool odd = lane & 1;
+    // stage-0 write slot of this lane (RAW): 252 kS/s sample m = 32j + half of the pass, own component:
+    // phase r = m & 7 = half & 7, entry XH + (m >> 3) = XH + 4j + (lane >> 4)
+    double *xw = (double *)&lds.X[(half & 7) * XS + XH + (lane >> 4)] + comp;
+    // 252 kS/s input: the lane holds samples 4*lane .. 4*lane+3 = phases 4*(lane & 1) + s of entry XH + (lane >> 1)
+    double2 *xw4 = &lds.X[(lane & 1) * 4 * XS + XH + half];
+    // FIR1 read base of this lane: sample 8*half + t is component comp of X[(t & 7) * XS + XH + half + floor(t / 8)]
+    const double *xr = (const double *)&lds.X[XH + half] + comp;
+    const lds_vdouble *xrv = (const lds_vdouble *)xr;
+    const int lane_mod9 = (2 * half) % 9;
+    // mixer: the 518 chain's I lanes and the 490 chain's Q lanes subtract the cross product (see step 4)
     static_assert(NVX_UNIT_SPLIT == 1 || NVX_UNIT_SPLIT == 3, "a unit must end with all pending buffers empty");
     const int n_units = a.n_streams * a.n_frames * NVX_UNIT_SPLIT;
+    double h1v[NVX_T1];
+#pragma unroll
+    for (int i = 0; i < NVX_T1; i++)
+        if (NVX_H1_FIRST.first[i] == i) { h1v[i] = NVX_H1[i]; asm volatile("" : "+v"(h1v[i])); }
 
     for (;;) {
         // ------------------------------------------------------ next unit
@@ -234,6 +309,10 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         const unsigned mask = a.chain_masks[stream];
         // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
         const int chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
+
+        // mixer table row of this lane: its cross term carries the sign of the 518 chain (I lanes negated) -- or, when the
+        // unit's only chain is the 490 one, of that chain (Q lanes negated); see step 4
+        const lds_vd2 *mixrow = (const lds_vd2 *)&lds.mix[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
 
         // independent units: rebuild the histories from the nine passes in front of the unit (nvx_kernels.h)
         const bool preroll = a.independent && part > 0;
@@ -283,8 +362,8 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         NVX_WAVE_LDS_FENCE();
         if (!preroll) {
             if (lane < 36) {                               // 36 newest 252 kS/s samples, oldest first
-                int e = lane >> 2, r = lane & 3;           // sample -36+lane = 4*(e-9) + r
-                lds.X[r * XS + e] = state_load(st_in + lane);
+                const int v = lane + 4;                    // sample -36+lane = 8*((v>>3) - XH) + (v&7)
+                lds.X[(v & 7) * XS + (v >> 3)] = state_load(st_in + lane);
             }
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -296,7 +375,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
             }
         } else {
             const double2 zero = { 0.0, 0.0 };
-            if (lane < 36) lds.X[(lane & 3) * XS + (lane >> 2)] = zero;
+            if (lane < XPH * XH) lds.X[(lane & 7) * XS + (lane >> 3)] = zero;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 for (int i = lane; i < 46 + NVX_PREROLL_U; i += 64) lds.U[c][i] = zero;
@@ -312,64 +391,114 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         bool emit = !preroll;                            // FIR3 outputs of the pre-roll are not written
         const size_t y3_row0 = (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_UNIT_Y3;
 
+#if NVX_PROBE == 9
+        unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_prev = __builtin_amdgcn_s_memtime();
+#endif
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
+            NVX_STAMP(0);                                  // loop control between passes
+#if NVX_PROBE == 9
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NVX_STAMP(1);                                  // waiting for this pass's input
+#endif
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
             if (RAW) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) xw[j * 16] = stage0_component(pf[j], odd);   // +8 double2 entries per load
+                for (int j = 0; j < 8; j++) xw[j * 8] = stage0_component(pf[j], odd);   // +4 double2 entries per load
             } else {
-                // lane holds samples 4*lane .. 4*lane+3 = phases 0..3 of index k' = lane
                 const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
+#if NVX_PROBE == 4
+                if ((w[0] ^ w[1] ^ w[2] ^ w[3]) == 0x12345678u) xw4[0] = double2{ 1.0, 1.0 };
+#else
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     double2 v;
                     v.x = (double)(int)(short)(w[r] & 0xffffu);       // capt_sched.c:511 (double) of each short
                     v.y = (double)((int)w[r] >> 16);
-                    lds.X[r * XS + 9 + lane] = v;
+                    xw4[r * XS] = v;
                 }
+#endif
             }
             // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
             if (pass + PFD < n_pass) load_pass<RAW, NT>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
 
-            // ---- 3. FIR1: y1[k] = sum_i h1[i] * x[4k+3-i] ----------------------
-            double aI = 0.0, aQ = 0.0;
+            NVX_STAMP(2);                                  // input conversion + window write + next load issued
+            // ---- 3. FIR1: y1[o] = sum_i h1[i] * x[4o+3-i], outputs o = 2*half and 2*half+1 of component comp.
+            // With s_j = x[8*half + 7 - j]:  y1[2*half+1] = sum_j h1[j] * s_j (j = 0..36),
+            //                               y1[2*half]   = sum_j h1[j-4] * s_j (j = 4..40): both in tap order.
+            // The reads run NVX_F1_AHEAD samples ahead of the arithmetic, so the LDS latency is covered by the wave's own
+            // fp64 work.  volatile: each read stays a ds_read_b64 (512 contiguous bytes per wave, 2 LDS cycles); merged
+            // into ds_read2_b64 a pair would cost 8 (MI355X_MICROARCH.md, LDS table).
+            // In front of them go the two reads whose results are only needed after FIR1 -- the mixer's table entries and
+            // the tail of the new samples that becomes the next pass's history -- so that neither costs a round trip
+            // through the LDS with the wave idle.
+            const nvx_d2 c0 = mixrow[mixbase], c1 = mixrow[mixbase + 1];
+            nvx_d2 tail = { 0.0, 0.0 };
+            if (lane < XPH * XH) tail = *(const lds_vd2 *)&lds.X[(lane & 7) * XS + 32 + (lane >> 3)];
+            double xs[NVX_T1 + 4];
+            constexpr int F1N = NVX_T1 + 4, F1NG = (F1N + NVX_F1_GROUP - 1) / NVX_F1_GROUP;
 #pragma unroll
-            for (int i = 0; i < NVX_T1; i++) {
-                const int q = i >> 2, r = 3 - (i & 3);
-                double2 x = xr[r * XS - q];
-                aI += NVX_H1[i] * x.x;
-                aQ += NVX_H1[i] * x.y;
-            }
-            // ---- 4. mixer, table index (k mod 9), k counted from the frame start
-            // (a frame is 20160 = 9 * 2240 FIR1 outputs, so that equals k from stream start)
-            int j9 = mixbase + lane_mod9; if (j9 >= NVX_MIX_N) j9 -= NVX_MIX_N;
-            const double cr = lds.mix[j9], ci = lds.mix[NVX_MIX_N + j9];
+            for (int j = 0; j < NVX_F1_AHEAD * NVX_F1_GROUP; j++) xs[j] = NVX_PROBE_READ(xrv[f1_offset(j)], j);
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const int ch = (NCH == 1) ? chain_of_slot0 : c;
-                double2 uu;
-                if (ch == 0) {                 // 518 chain, fir2cpp.C:116-117
-                    uu.x = aI * cr - aQ * ci;
-                    uu.y = aI * ci + aQ * cr;
-                } else {                       // 490 chain, fir2cpp.C:122-123
-                    uu.x = aI * cr + aQ * ci;
-                    uu.y = -aI * ci + aQ * cr;
+            for (int g = 0; g < F1NG; g++) {
+                // reads of group g + AHEAD go out behind the arithmetic of group g - 1 ...
+                if (g + NVX_F1_AHEAD < F1NG) {
+                    NVX_PIN_AFTER(a1);
+#pragma unroll
+                    for (int j = (g + NVX_F1_AHEAD) * NVX_F1_GROUP; j < (g + NVX_F1_AHEAD + 1) * NVX_F1_GROUP && j < F1N; j++) xs[j] = NVX_PROBE_READ(xrv[f1_offset(j)], j);
                 }
-                lds.U[c][46 + n_u + lane] = uu;
+                // ... and one wait covers a whole group (LDS reads return in order): its first value "depends" on its last
+                const int lo = g * NVX_F1_GROUP, hi = (lo + NVX_F1_GROUP < F1N ? lo + NVX_F1_GROUP : F1N) - 1;
+                if (hi > lo) asm volatile("" : "+v"(xs[lo]) : "v"(xs[hi]));
+#pragma unroll
+                for (int j = lo; j <= hi; j++) {
+#if NVX_PROBE == 2 || NVX_PROBE == 7
+                    a1 = __hiloint2double(__double2hiint(a1) ^ __double2hiint(xs[j]), __double2loint(a1));
+#else
+                    if (j < NVX_T1) a1 += h1v[NVX_H1_FIRST.first[j]] * xs[j];
+                    if (j >= 4) a0 += h1v[NVX_H1_FIRST.first[j - 4]] * xs[j];
+#endif
+                }
             }
+            NVX_STAMP(3);                                  // FIR1
+            // ---- 4. mixer, table index (o mod 9), o counted from the frame start
+            // (a frame is 20160 = 9 * 2240 FIR1 outputs, so that equals o from stream start).
+            // 518 chain (fir2cpp.C:116-117): (I*cr - Q*ci, I*ci + Q*cr); 490 chain (:122-123): (I*cr + Q*ci, -I*ci + Q*cr).
+            // A lane owns one component of its two outputs and gets the other from its partner lane (DPP pair swap).
+            // With A = mine*cr and B = other*ci, both chains' results are A + B or A - B (a sum commutes exactly and
+            // (-I)*ci = -(I*ci) exactly): 518 -> I lane A - B, Q lane A + B; 490 -> I lane A + B, Q lane A - B.
+#if NVX_PROBE == 5
+            if (__double2hiint(a0) == 0x12345678 && __double2hiint(a1) == 0x12345678 && c0.x == 3.0 && c1.x == 3.0) lds.U[0][0] = double2{ 1.0, 1.0 };
+#else
+            {
+                const double o0 = dpp_swap_pairs_f64(a0), o1 = dpp_swap_pairs_f64(a1);
+                const double A0 = a0 * c0.x, A1 = a1 * c1.x;
+                // the lane's table row holds +-ci: B carries the sign of the 518 chain (of the unit's only chain when
+                // NCH == 1); with two chains the 490 one takes the opposite sign
+                const double B0 = o0 * c0.y, B1 = o1 * c1.y;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const int ch = (NCH == 1) ? chain_of_slot0 : c;
+                    double *uw = (double *)&lds.U[c][46 + n_u + 2 * half] + comp;
+                    uw[0] = (NCH == 1 || ch == 0) ? A0 + B0 : A0 - B0;
+                    uw[2] = (NCH == 1 || ch == 0) ? A1 + B1 : A1 - B1;
+                }
+            }
+#endif
             n_u += 64;
             mixbase += 1; if (mixbase == NVX_MIX_N) mixbase = 0;      // 64 mod 9 == 1
-            // ---- 5. slide the 9-deep history of each phase to the front --------
+            // ---- 5. slide the 5-deep history of each phase to the front --------
             NVX_WAVE_LDS_FENCE();
-            if (lane < 36) {
-                int e = lane >> 2, r = lane & 3;
-                double2 t = lds.X[r * XS + 64 + e];
-                lds.X[r * XS + e] = t;
-            }
+#if NVX_PROBE == 6
+            if (lane < XPH * XH && tail.x == 1.2345) *(lds_vd2 *)&lds.X[(lane & 7) * XS + (lane >> 3)] = tail;
+#else
+            if (lane < XPH * XH) *(lds_vd2 *)&lds.X[(lane & 7) * XS + (lane >> 3)] = tail;
+#endif
             NVX_WAVE_LDS_FENCE();
 
+            NVX_STAMP(4);                                  // mixer + slide
             // ---- 6. FIR2 when a batch of mixer outputs is pending -----------------
             constexpr int U_RUN = Geo<NCH>::U_RUN, Y2_PER_RUN = Geo<NCH>::Y2_PER_RUN;
             constexpr int Y2_RUN = Geo<NCH>::Y2_RUN, Y3_PER_RUN = Geo<NCH>::Y3_PER_RUN;
@@ -377,12 +506,27 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
             // two chains put chain 0 on lanes 0-31 and chain 1 on lanes 32-63 (16 outputs each)
             const int f2c = (NCH == 2) ? (lane >> 5) : 0;
             const int f2o = (NCH == 2) ? ((lane >> 1) & 15) : half;
+#if NVX_PROBE == 3
+            if (n_u >= U_RUN) { n_u -= U_RUN; n_y2 += Y2_PER_RUN; if (n_y2 >= Y2_RUN) { n_y2 -= Y2_RUN; n3_done += Y3_PER_RUN; } }
+#endif
             while (n_u >= U_RUN) {
-                {
-                    const double *ub = (const double *)&lds.U[f2c][7 * f2o] + comp;
-                    double acc = 0.0;
+                // the pending entries behind this run move to the front afterwards: read them now, write them after the FIR
+                nvx_d2 ut0[NCH], ut1[NCH];
 #pragma unroll
-                    for (int i = 0; i < NVX_T2; i++) acc += NVX_H2[i] * ub[2 * (52 - i)];
+                for (int c = 0; c < NCH; c++) {
+                    ut0[c] = *(const lds_vd2 *)&lds.U[c][U_RUN + lane];
+                    ut1[c] = *(const lds_vd2 *)&lds.U[c][U_RUN + 64 + ((lane < 45) ? lane : 44)];
+                }
+                {
+                    const lds_vdouble *ub = (const lds_vdouble *)((const double *)&lds.U[f2c][7 * f2o] + comp);
+                    double xs[NVX_T2], acc = 0.0;                 // reads run ahead of the arithmetic, as in FIR1
+#pragma unroll
+                    for (int i = 0; i < NVX_F23_AHEAD; i++) xs[i] = ub[2 * (52 - i)];
+#pragma unroll
+                    for (int i = 0; i < NVX_T2; i++) {
+                        if (i + NVX_F23_AHEAD < NVX_T2) { NVX_PIN_AFTER(acc); xs[i + NVX_F23_AHEAD] = ub[2 * (52 - (i + NVX_F23_AHEAD))]; }
+                        acc += NVX_H2[i] * xs[i];
+                    }
                     if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds.Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
                 }
                 NVX_WAVE_LDS_FENCE();
@@ -390,11 +534,8 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                 const int keep = 46 + n_u - U_RUN;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
-                    double2 t0 = lds.U[c][U_RUN + lane];
-                    double2 t1 = lds.U[c][U_RUN + 64 + ((lane < 45) ? lane : 44)];
-                    NVX_WAVE_LDS_FENCE();
-                    if (lane < keep) lds.U[c][lane] = t0;
-                    if (lane + 64 < keep) lds.U[c][64 + lane] = t1;
+                    if (lane < keep) *(lds_vd2 *)&lds.U[c][lane] = ut0[c];
+                    if (lane + 64 < keep) *(lds_vd2 *)&lds.U[c][64 + lane] = ut1[c];
                 }
                 NVX_WAVE_LDS_FENCE();
                 n_u -= U_RUN;
@@ -407,12 +548,23 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                     const int f3c = (NCH == 2) ? ((lane >> 4) & 1) : 0;
                     const int f3o = half & (Y3_PER_RUN - 1);
                     const bool f3live = lane < 2 * Y3_PER_RUN * NCH;
+                    nvx_d2 yt0[NCH], yt1[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        yt0[c] = *(const lds_vd2 *)&lds.Y2[c][Y2_RUN + lane];
+                        yt1[c] = *(const lds_vd2 *)&lds.Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36) * (NCH == 1) + ((lane < 21) ? lane : 20) * (NCH == 2)];
+                    }
                     {
                         const int ch = (NCH == 1) ? chain_of_slot0 : f3c;
-                        const double *yb = (const double *)&lds.Y2[f3c][10 * f3o] + comp;
-                        double acc = 0.0;
+                        const lds_vdouble *yb = (const lds_vdouble *)((const double *)&lds.Y2[f3c][10 * f3o] + comp);
+                        double xs[NVX_T3], acc = 0.0;
 #pragma unroll
-                        for (int i = 0; i < NVX_T3; i++) acc += NVX_H3[i] * yb[2 * (79 - i)];
+                        for (int i = 0; i < NVX_F23_AHEAD; i++) xs[i] = yb[2 * (79 - i)];
+#pragma unroll
+                        for (int i = 0; i < NVX_T3; i++) {
+                            if (i + NVX_F23_AHEAD < NVX_T3) { NVX_PIN_AFTER(acc); xs[i + NVX_F23_AHEAD] = yb[2 * (79 - (i + NVX_F23_AHEAD))]; }
+                            acc += NVX_H3[i] * xs[i];
+                        }
                         if (emit && f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
                             double *out = (double *)(a.y3 + (y3_row0 + (size_t)ch * a.y3_cap + n3_done + f3o));
                             out[comp] = acc;
@@ -422,17 +574,15 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
                     const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101 (one chain) / 85 (two chains)
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
-                        double2 t0 = lds.Y2[c][Y2_RUN + lane];
-                        double2 t1 = lds.Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36) * (NCH == 1) + ((lane < 21) ? lane : 20) * (NCH == 2)];
-                        NVX_WAVE_LDS_FENCE();
-                        if (lane < keep3) lds.Y2[c][lane] = t0;
-                        if (lane + 64 < keep3) lds.Y2[c][64 + lane] = t1;
+                        if (lane < keep3) *(lds_vd2 *)&lds.Y2[c][lane] = yt0[c];
+                        if (lane + 64 < keep3) *(lds_vd2 *)&lds.Y2[c][64 + lane] = yt1[c];
                     }
                     NVX_WAVE_LDS_FENCE();
                     n_y2 -= Y2_RUN;
                     n3_done += Y3_PER_RUN;
                 }
             }
+            NVX_STAMP(5);                                  // FIR2 / FIR3
         };
 
         if (PFD == 2) {
@@ -449,13 +599,17 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
             }
         }
 
+#if NVX_PROBE == 9
+        if (lane == 0 && blockIdx.x < 24 && u < 4096)
+            printf("PH wg %d unit %d: loop %llu inwait %llu input %llu fir1 %llu mix %llu fir23 %llu\n", (int)blockIdx.x, u, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+#endif
         // ------------------------------------------------------ state out
         // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
         if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) {
             if (lane < 36) {
-                int e = lane >> 2, r = lane & 3;
-                state_store(st + lane, lds.X[r * XS + e]);
+                const int v = lane + 4;
+                state_store(st + lane, lds.X[(v & 7) * XS + (v >> 3)]);
             }
 #pragma unroll
             for (int c = 0; c < NCH; c++) {

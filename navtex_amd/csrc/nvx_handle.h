@@ -77,6 +77,12 @@ struct nvx_handle {
     hipEvent_t casc_done[2] = { nullptr, nullptr };   // y3[b] written
     hipEvent_t demod_done[2] = { nullptr, nullptr };  // y3[b] consumed
     hipEvent_t fsm_done = nullptr; bool fsm_pending = false;   // word buffer consumed
+    // Everything a launch carries (work queue, cascade state, demodulator state, word buffer) is ordered by stream
+    // order on the launch stream.  launch_done is recorded behind the last operation of every launch; a launch on a
+    // DIFFERENT stream than its predecessor waits for it, and reset / enable_debug / destroy wait for it on the host,
+    // so a caller may pass any stream to nvx_process_resident at any time.
+    hipEvent_t launch_done = nullptr; bool launch_done_valid = false;
+    hipStream_t last_launch_stream = nullptr;
     bool demod_pending[2] = { false, false };
     // device
     uint8_t *d_masks = nullptr, *d_active = nullptr;
@@ -117,6 +123,8 @@ struct SinkCtx { nvx_handle *h; int stream; int slot; };
 // launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
                       bool input_on_stream3 = false);
+// nvx_push_iq that reports how many samples it staged before NVX_ERR_FULL (or another error) stopped it
+int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted);
 // wait for every launched block, append bits, run the character layer (handle locked)
 int nvx_collect_locked(nvx_handle *h);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries

@@ -33,9 +33,11 @@ static int submit_locked(nvx_handle *h)
     return NVX_OK;
 }
 
+// accepted (optional): how many of the n samples were staged -- all of them on NVX_OK, fewer on NVX_ERR_FULL
 template <typename F>
-static int push_common(nvx_handle *h, int stream, size_t n, F copy_in)
+static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *accepted = nullptr)
 {
+    if (accepted) *accepted = 0;
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::lock_guard<std::mutex> lk(h->mu);
@@ -47,16 +49,27 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in)
             int rc = submit_locked(h);
             if (rc != NVX_OK) return rc;
             room = h->stage_cap - h->fill[stream];
-            if (room == 0) { nvx_set_error("stream %d is a whole staging buffer ahead of the slowest stream", stream); return NVX_ERR_FULL; }
+            if (room == 0) {
+                nvx_set_error("stream %d is a whole staging buffer ahead of the slowest stream", stream);
+                if (accepted) *accepted = done;
+                return NVX_ERR_FULL;
+            }
         }
         size_t m = std::min(room, n - done);
         copy_in(h->h_stage[h->cur] + (size_t)stream * h->stage_cap + h->fill[stream], done, m);
         h->fill[stream] += m;
         done += m;
         size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
-        if (minfill >= h->frame_in) { int rc = submit_locked(h); if (rc != NVX_OK) return rc; }
+        if (minfill >= h->frame_in) { int rc = submit_locked(h); if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; } }
     }
+    if (accepted) *accepted = n;
     return NVX_OK;
+}
+
+// the capture ring's consumer: a full staging set is back-pressure there, not an error
+int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted)
+{
+    return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) { memcpy(dst, iq + 2 * off, m * 4); }, accepted);
 }
 
 extern "C" int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq, size_t n)
