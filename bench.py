@@ -9,15 +9,21 @@ stage 0 (/8) -> FIR1 -> mixer -> FIR2 -> FIR3 -> FSK discriminator -> bit sync
 
 One "step" = one pass of that path over the whole resident batch
 (streams x frames x 645120 samples).  Multi-GPU: one process per GPU
-(torch.distributed / RCCL only for the barrier and the max-over-ranks of the
-elapsed time); streams shard one subset per GPU, no data-path collective,
-weak scaling.
+(torch.distributed / RCCL only for the barrier, the max-over-ranks of the
+elapsed time and the min-over-ranks of the parity verdict); streams shard one
+subset per GPU, no data-path collective, weak scaling.
+
+Every rank checks its OWN shard against the oracle before the timed region (all
+streams at N = 1, a spread sample of them per rank otherwise); the line's
+`parity` is the minimum over ranks, and a failed parity makes the process exit
+with status 3 after printing the line.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -32,6 +38,16 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 BYTES_PER_SAMPLE = 4           # int16 I + int16 Q, each read from HBM exactly once
+# fp64 roof of the 252 kS/s kernels: the reference's arithmetic is mul-then-add, never fused, so the roof is the
+# fp64 ISSUE rate: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (a wave64 fp64 instruction takes 4 cycles)
+FP64_NOFMA_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12            # 39.3
+# fp64 operations per 252 kS/s complex input sample: FIR1 37 taps x 2 components x (mul + add) / 4, then per chain
+# mixer 6 / 4, FIR2 47 x 2 x 2 / 28, FIR3 71 x 2 x 2 / 280   
+FLOP_FIR1, FLOP_PER_CHAIN = 37.0, 6 / 4 + 47 * 4 / 28 + 71 * 4 / 280
+
+
+def flops_per_sample(chains: int) -> float:
+    return FLOP_FIR1 + chains * FLOP_PER_CHAIN
 
 
 def parse():
@@ -43,6 +59,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=12, help="frames (0.32 s each) resident per stream")
     ap.add_argument("--cpu-streams", type=int, default=0, help="streams in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--verify", type=int, default=-1, metavar="N",
+                    help="streams per rank checked against the oracle before the timed region (-1 = all at N = 1 on the "
+                         "headline workload, 32 spread over the shard otherwise; 0 is not accepted: an unchecked number is no number)")
     ap.add_argument("--no-charlayer", action="store_true")
     ap.add_argument("--pitch-pad", type=int, default=0, help="extra complex samples between streams (multiple of 4)")
     ap.add_argument("--wideband", type=int, default=0, metavar="W",
@@ -52,6 +71,71 @@ def parse():
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
     return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- host placement (no GPU call in here)
+def _parse_cpulist(text: str) -> set:
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _gpu_numa(dev: int):
+    """(numa node, local CPU set) of HIP device `dev`, from the KFD topology in sysfs; (None, None) when unknown.
+    No HIP call: the affinity must be in place before the runtime starts its own threads."""
+    try:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis and all(v.strip().isdigit() for v in vis.split(",")):
+            dev = int(vis.split(",")[dev])
+        gpus = []
+        for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(os.path.basename(p))):
+            props = dict(line.split(None, 1) for line in open(os.path.join(node, "properties")).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        minor = int(gpus[dev]["drm_render_minor"])
+        base = f"/sys/class/drm/renderD{minor}/device"
+        return int(open(base + "/numa_node").read()), _parse_cpulist(open(base + "/local_cpulist").read())
+    except Exception:
+        return None, None
+
+
+def place_rank(device: int, local_world: int, local_rank: int):
+    """Bind this process to the CPUs of its GPU's NUMA node and size its host thread pools from its share of them."""
+    numa, cpus = _gpu_numa(device)
+    have = os.sched_getaffinity(0)
+    bound = False
+    if cpus:
+        both = have & cpus
+        if both:
+            try:
+                os.sched_setaffinity(0, both); have = both; bound = True
+            except OSError:
+                pass
+    # ranks of this node that share the NUMA node (devices are dealt in rank order)
+    sharing = 1
+    if local_world > 1:
+        mine = numa
+        sharing = sum(1 for r in range(local_world) if _gpu_numa(r)[0] == mine) if mine is not None else local_world
+        sharing = max(1, sharing)
+    threads = max(1, min(16, len(have) // sharing))
+    # one GPU of the pool's boxes comes with a 16-thread CPU share whatever the affinity mask says
+    threads = int(os.environ.get("NVX_CPU_THREADS", threads))
+    os.environ.setdefault("NVX_HOST_THREADS", str(threads))            # the library's character-layer pool
+    return {"numa_node": numa, "bound": bound, "cpus": len(have), "ranks_on_numa_node": sharing, "threads": threads}
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def reference_check(ob, raw_stream):
@@ -99,92 +183,116 @@ def wideband_streams(nv, signals, rank, W, n_phasing=40):
     return out
 
 
-def run_wideband(args, nv, signals, torch, dist, rank, world, device, backend):
+class Ranks:
+    """The few collectives the benchmark needs: barrier, max / min / sum of a number over the ranks."""
+
+    def __init__(self, torch, dist, device, backend):
+        self.torch, self.dist, self.device, self.backend = torch, dist, device, backend
+
+    def sync(self):
+        if self.device is not None:                  # None: CPU-only test of the orchestration
+            self.torch.cuda.synchronize(self.device)
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.device is not None:
+                self.torch.cuda.synchronize(self.device)
+
+    def reduce(self, value: float, op: str) -> float:
+        if self.dist is None:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=f"cuda:{self.device}" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+
+def finish(line, parity, ranks, rank):
+    """Print the line on rank 0; a failed parity is a failed run (exit status 3) on every rank."""
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if ranks.dist is not None:
+        ranks.dist.barrier()
+        ranks.dist.destroy_process_group()
+    if not parity:
+        sys.exit(3)
+
+
+def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     """Channeliser + 252 kS/s pipeline on W wideband streams per GPU."""
+    import oracle_binding as ob
     W, F = args.wideband, args.frames
     n_raw, n_sub = F * nv.FRAME_RAW, F * nv.FRAME_IN
     t0 = time.time()
     raw = nv.DeviceBuffer(W * n_raw * 4, device=device)
-    sub = None
     nv.synth_device(wideband_streams(nv, signals, rank, W), nv.RATE_RAW, n_raw, raw, n_raw)
     t_gen = time.time() - t0
-    # wideband handle: channeliser (own stream, double-buffered sub-bands) + 252 kS/s path; the channeliser
-    # of step k+1 overlaps the cascade of step k
     pipe = nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device)
-    del sub
 
     def step():
         pipe.process_resident(raw, n_raw, 0, F)
 
-    def sync_all():
-        torch.cuda.synchronize(device)
-        if dist is not None:
-            dist.barrier(); torch.cuda.synchronize(device)
-
-    cpu, parity = None, None
-    if rank == 0:
-        import oracle_binding as ob
-        ncpu = int(os.environ.get("NVX_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
-        nw = min(W, 2 if world > 1 else max(2, ncpu // 4))
-        sample = raw.download(nw * n_raw * 4, dtype=np.int16).reshape(nw, n_raw, 2)
-        step(); pipe.fetch()
-        gpu_bits = [pipe.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
-        sN, cpu_bits = ob.bench_wide(sample, nw, n_sub, ncpu, want_bits=True)
-        if not args.no_cpu and world == 1:
-            rep = max(1, int(5.0 / max(sN, 1e-3)))
-            sN = ob.bench_wide(sample, nw, n_sub, ncpu, repeat=rep)[0]
-            s1 = ob.bench_wide(sample[:1], 1, n_sub, 1, repeat=max(1, rep // 8))[0]
-            cpu = {"value": round(nw * n_raw * rep / sN / 1e6, 2), "unit": "Msamples/s", "cores": ncpu, "kind": "port",
-                   "value_1thread": round(n_raw * max(1, rep // 8) / s1 / 1e6, 2),
-                   "sample": f"all {F} frames of the first {nw} wideband streams ({nw * n_raw / 1e6:.0f} M raw samples), processed {rep}x; "
-                             f"oracle channeliser + 8 x 2-chain 252 kS/s pipes, OpenMP over streams", "seconds": round(sN, 2)}
-        parity = gpu_bits == cpu_bits and all(len(b) > 0 for b in cpu_bits)
-        if not parity:
-            print("PARITY FAILURE (wideband): GPU bits differ from the CPU oracle", file=sys.stderr)
+    # ---- parity: every rank, the first nw wideband streams of its shard (16 carriers each) against the oracle chain
+    ncpu = place["threads"]
+    nw = min(W, max(2, (args.verify if args.verify > 0 else 32) // 16))
+    sample = raw.download(nw * n_raw * 4, dtype=np.int16).reshape(nw, n_raw, 2)
+    step(); pipe.fetch()
+    gpu_bits = [pipe.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
+    sN, cpu_bits = ob.bench_wide(sample, nw, n_sub, ncpu, want_bits=True)
+    ok = gpu_bits == cpu_bits and all(len(b) > 0 for b in cpu_bits)
+    if not ok:
+        print(f"PARITY FAILURE (wideband, rank {rank}): GPU bits differ from the CPU oracle", file=sys.stderr)
+    parity = ranks.reduce(1.0 if ok else 0.0, "min") > 0.5
+    checked = int(ranks.reduce(16.0 * nw, "sum"))
+    near_ties = int(ranks.reduce(float(pipe.tie_stats()[0]), "sum"))
+    cpu = None
+    if rank == 0 and not args.no_cpu and world == 1:
+        rep = max(1, int(5.0 / max(sN, 1e-3)))
+        sN = ob.bench_wide(sample, nw, n_sub, ncpu, repeat=rep)[0]
+        s1 = ob.bench_wide(sample[:1], 1, n_sub, 1, repeat=max(1, rep // 8))[0]
+        cpu = {"value": round(nw * n_raw * rep / sN / 1e6, 2), "unit": "Msamples/s", "cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
+               "value_1thread": round(n_raw * max(1, rep // 8) / s1 / 1e6, 2),
+               "sample": f"all {F} frames of the first {nw} wideband streams ({nw * n_raw / 1e6:.0f} M raw samples), processed {rep}x; "
+                         f"oracle channeliser + 8 x 2-chain 252 kS/s pipes, OpenMP over streams", "seconds": round(sN, 2)}
     pipe.reset()
     for _ in range(args.warmup):
         step()
     pipe.fetch()
     pipe.enable_timing(True); pipe.kernel_time_stats(0, reset=True)
     nv.lib.nvx_channelise_timing(1); nv.channelise_time_stats(reset=True)
-    sync_all()
+    ranks.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     pipe.fetch()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ranks.sync()
+    elapsed = ranks.reduce(time.perf_counter() - t0, "max")
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
     ch_ms, n_c = nv.channelise_time_stats()
-    if rank == 0:
-        casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
-        sub_bytes = 8 * W * n_sub * 4
-        line = {
-            "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(world * W * n_raw * args.steps / elapsed / 1e6, 1),
-            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"WIDEBAND (SURVEY 8f-2, not the headline): {W} streams x 2.016 MS/s per GPU, 16 NAVTEX carriers each "
-                                   f"(8 sub-bands x 2 chains), {F} frames ({F * 0.32:.2f} s) resident in HBM",
-                       "wide_streams_per_gpu": W, "carriers_per_gpu": 16 * W, "frames": F,
-                       "parallelism": f"wideband streams sharded {world} ways, no collective"},
-            "carriers_decoded": 16 * W * world,
-            "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
-            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<252k,2>", "achieved": round(sub_bytes / (casc_avg * 1e-3) / 1e9, 1) if casc_avg else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sub_bytes / (casc_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if casc_avg else None,
-                         "traffic": None, "algorithmic_bytes_per_launch": sub_bytes, "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),
-                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
-                         "note": "fp64-issue-bound by design at 252 kS/s (DESIGN.md 3.1, Variant A)"},
-            "channeliser": {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
-                            "read_plus_write_gbs": round((W * n_raw * 4 + sub_bytes) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
-            "cpu_baseline": cpu, "parity": parity, "gen_seconds": round(t_gen, 1),
-        }
-        print(json.dumps(line), flush=True)
+    casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
+    sub_samples = 8 * W * n_sub
+    tops = flops_per_sample(2) * sub_samples / (casc_avg * 1e-3) / 1e12 if casc_avg else None
+    line = {
+        "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(world * W * n_raw * args.steps / elapsed / 1e6, 1),
+        "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"WIDEBAND (SURVEY 8f-2, not the headline): {W} streams x 2.016 MS/s per GPU, 16 NAVTEX carriers each "
+                               f"(8 sub-bands x 2 chains), {F} frames ({F * 0.32:.2f} s) resident in HBM",
+                   "wide_streams_per_gpu": W, "carriers_per_gpu": 16 * W, "frames": F,
+                   "parallelism": f"wideband streams sharded {world} ways, no collective"},
+        "carriers_decoded": 16 * W * world,
+        "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
+        "roofline": {"bound": "fp64_valu", "kernel": "nvx_fir_cascade<252k,2>", "achieved": round(tops, 2) if tops else None,
+                     "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
+                     "traffic": None, "flop_per_sample": round(flops_per_sample(2), 2), "samples_per_launch": sub_samples,
+                     "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
+                     "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes"},
+        "channeliser": {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
+                        "read_plus_write_gbs": round((W * n_raw * 4 + sub_samples * 4) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
+        "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "demod": {"near_ties": near_ties},
+        "host_threads": place["threads"], "placement": place, "gen_seconds": round(t_gen, 1),
+    }
     pipe.close(); raw.free()
+    finish(line, parity, ranks, rank)
 
 
 def main():
@@ -192,17 +300,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    if args.verify == 0:
+        raise SystemExit("--verify 0: an unchecked number is no number")
 
-    import torch
-    dist = None
     # NVX_BENCH_BACKEND=gloo / NVX_BENCH_DEVICE=<n>: rehearsal of the multi-process path on a box
     # with fewer GPUs than ranks (RCCL refuses two ranks on one device); never used by the driver.
     backend = os.environ.get("NVX_BENCH_BACKEND", "nccl")
     device = int(os.environ.get("NVX_BENCH_DEVICE", local))
+    # host placement first: the affinity is inherited by every thread the HIP runtime, RCCL and the library start
+    place = place_rank(device, local_world, local)
+
+    import torch
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,26 +326,27 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if not (ROOT / "navtex_amd" / "libnavtex_amd.so").exists():       # fresh checkout: build first (hipcc, gfx950)
-        import importlib.util
+    # fresh checkout: rank 0 builds (hipcc, gfx950; linked beside the target and renamed), everybody else waits at the
+    # barrier -- which every rank reaches whatever it sees on disk, so the collectives stay paired
+    if rank == 0 and not (ROOT / "navtex_amd" / "libnavtex_amd.so").exists():
+        import contextlib, importlib.util
         spec = importlib.util.spec_from_file_location("nvx_build", ROOT / "navtex_amd" / "build.py")
         mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-        if rank == 0:
-            import contextlib
-            with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
-                mod.build_lib()
-        if dist is not None:
-            dist.barrier()
+        with contextlib.redirect_stdout(sys.stderr):       # stdout carries exactly one JSON line
+            mod.build_lib()
+    if dist is not None:
+        dist.barrier()
     import navtex_amd as nv
     import signals
 
     if nv.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: navtex_amd has no CPU path")
+    ranks = Ranks(torch, dist, device, backend)
     if args.wideband:
-        run_wideband(args, nv, signals, torch, dist, rank, world, device, backend)
-        if dist is not None:
-            dist.barrier(); dist.destroy_process_group()
+        run_wideband(args, nv, signals, ranks, rank, world, device, place)
         return
+    import oracle_binding as ob
+    import fullsize
     S, F = args.streams, args.frames
     raw = not args.variant_a
     RATE, FRAME = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)
@@ -253,58 +368,46 @@ def main():
 
     pipe = nv.Pipeline(n_streams=S, raw_rate=raw, chain_mask=nv.CHAIN_518, max_frames=F,
                        char_layer=not args.no_charlayer, device=device)
+    ncpu = place["threads"]
 
-    def sync_all():
-        torch.cuda.synchronize(device)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(device)
+    # ---- parity gate: EVERY rank checks its own shard against the oracle, from reset state -----------------------
+    pipe.process_resident(buf, pitch, 0, F)
+    pipe.fetch()
+    n_verify = args.verify if args.verify > 0 else (S if (world == 1 and raw) else 32)
+    ids = fullsize.spread(S, n_verify)
+    checked, bad, verify_s = fullsize.verify_streams(ob, buf, pitch, n_per_stream, raw, lambda s: pipe.bits(s, 0), ids, ncpu)
+    if bad:
+        print(f"PARITY FAILURE (rank {rank}): {len(bad)} of {checked} streams differ from the CPU oracle, first {bad[:8]}", file=sys.stderr)
+    parity = ranks.reduce(0.0 if bad else 1.0, "min") > 0.5
+    checked_all = int(ranks.reduce(float(checked), "sum"))
+    near, evals, margin = pipe.tie_stats()
+    near_all = int(ranks.reduce(float(near), "sum"))
+    margin_all = ranks.reduce(margin if evals else 1.0, "min")
 
-    # ---- parity gate + CPU baseline (rank 0, N = 1 leg of the contract) ------
+    # ---- CPU baseline (rank 0, N = 1 leg of the contract) ---------------------------------------------------------
     cpu = None
-    parity = None
-    if rank == 0:
-        import oracle_binding as ob
-        # the GPU box gives one GPU a 16-thread CPU share whatever the affinity mask says
-        ncpu = int(os.environ.get("NVX_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
+    if rank == 0 and not args.no_cpu and world == 1:
         n_cs = min(args.cpu_streams or 2 * ncpu, S)
-        cf = F                         # whole batch length: every cascade dispatch of this run has the same shape
-        # the sample = the first cf frames of the first n_cs streams, copied back from HBM
-        sample = np.empty((n_cs, cf * FRAME, 2), dtype=np.int16)
+        sample = np.empty((n_cs, n_per_stream, 2), dtype=np.int16)
         for s in range(n_cs):
-            sample[s] = buf.download(cf * FRAME * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
-        # GPU bits for the same frames, from reset state
-        pipe.process_resident(buf, pitch, 0, cf)
-        pipe.fetch()
-        gpu_bits = [pipe.bits(s, 0) for s in range(n_cs)]
-        if not args.no_cpu and world == 1:
-            n252 = cf * nv.FRAME_IN
-            per_pass = n_cs * cf * FRAME
-            # calibrate, then size the repeat count for ~6 s wall on all threads (~100 core-seconds
-            # at 16 threads would exceed the "few minutes" budget; this is ~6 s x ncpu core-seconds)
-            sN, cpu_bits = ob.bench(sample, n_cs, n252, raw, 1, ncpu, want_bits=True)
-            rep = max(1, int(6.0 / max(sN, 1e-3)))
-            sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu, repeat=rep)[0]
-            one = min(n_cs, 2)
-            s1 = ob.bench(sample[:one], one, n252, raw, 1, 1, repeat=max(1, rep // 8))[0]
-            cpu = {
-                "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
-                "cores": ncpu, "kind": "port",
-                "value_1thread": round(one * cf * FRAME * max(1, rep // 8) / s1 / 1e6, 2),
-                "sample": f"all {cf} frames of the first {n_cs} streams of the bench batch ({per_pass / 1e6:.0f} M raw samples), "
-                          f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
-                "seconds": round(sN, 2),
-            }
-            cpu["reference_check"] = reference_check(ob, sample[0])
-        else:
-            cpu_bits = []
-            for s in range(n_cs if world == 1 else min(n_cs, 4)):
-                o = ob.Pipe(chain_mask=1, charlayer=False)
-                (o.push_raw if raw else o.push)(sample[s])
-                cpu_bits.append(o.bits(0))
-        parity = all(g == c for g, c in zip(gpu_bits, cpu_bits)) and len(cpu_bits) > 0 and all(len(c) > 0 for c in cpu_bits)
-        if not parity:
-            print("PARITY FAILURE: GPU bits differ from the CPU oracle", file=sys.stderr)
+            sample[s] = buf.download(n_per_stream * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+        n252 = F * nv.FRAME_IN
+        per_pass = n_cs * n_per_stream
+        # calibrate, then size the repeat count for ~6 s wall on all threads
+        sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu)[0]
+        rep = max(1, int(6.0 / max(sN, 1e-3)))
+        sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu, repeat=rep)[0]
+        one = min(n_cs, 2)
+        s1 = ob.bench(sample[:one], one, n252, raw, 1, 1, repeat=max(1, rep // 8))[0]
+        cpu = {
+            "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
+            "cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
+            "value_1thread": round(one * n_per_stream * max(1, rep // 8) / s1 / 1e6, 2),
+            "sample": f"all {F} frames of the first {n_cs} streams of the bench batch ({per_pass / 1e6:.0f} M raw samples), "
+                      f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
+            "seconds": round(sN, 2),
+        }
+        cpu["reference_check"] = reference_check(ob, sample[0]) if raw else None
     pipe.reset()
 
     # ---- warm-up, then EXACTLY K timed steps ------------------------------------
@@ -317,69 +420,73 @@ def main():
     pipe.enable_timing(True)
     pipe.kernel_time_stats(0, reset=True)
     pipe.wait_stats(reset=True)
-    sync_all()
+    ranks.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     pipe.fetch()                       # all launches done, bits on the host, characters decoded
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ranks.sync()
+    elapsed = ranks.reduce(time.perf_counter() - t0, "max")
 
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
     w_polls, w_units, w_launches = pipe.wait_stats()
     total_bits = sum(pipe.bit_count(s, 0) for s in range(0, S, max(1, S // 64)))
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * samples_per_step * args.steps / elapsed / 1e6
-        casc_avg = casc_ms / max(n_l, 1)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * samples_per_step * args.steps / elapsed / 1e6
+    casc_avg = casc_ms / max(n_l, 1)
+    handoff = {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4),
+               "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)}
+    if raw:
         achieved = bytes_per_step / (casc_avg * 1e-3) / 1e9 if casc_avg > 0 else None
-        traffic = None
+        traffic, traffic_source = None, None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text())
-                if raw and rec.get("streams") == S and rec.get("frames") == F:
+                if rec.get("streams") == S and rec.get("frames") == F:
                     traffic = rec.get("bytes_per_launch")
+                    traffic_source = "profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured by this run)"
             except Exception:
                 traffic = None
-        line = {
-            "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(value, 1), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, "
-                                    f"{F} frames ({F * 0.32:.2f} s) resident in HBM (BASELINE configs[3]; x{world} GPUs = configs[4] shape)") if raw else
-                                   (f"VARIANT A (not the headline): {S} channels x 252 kS/s int16 IQ per GPU, {F} frames ({F * 0.32:.2f} s), "
-                                    f"no stage 0 -- fp64-issue-bound by design (SURVEY 7-2)"),
-                       "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step,
-                       "stage0": "integrate-and-dump /8 (build-owned)" if raw else "none", "chains_per_stream": 1,
-                       "parallelism": f"streams sharded {world} ways, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>" if raw else "nvx_fir_cascade<252k,1>", "achieved": round(achieved, 1) if achieved else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_step,
-                         "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l),
-                         "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
-                         # hand-over of filter state between the frames of a stream: share of units that had to
-                         # wait for their predecessor and the average wait of those (one poll ~ 1 us)
-                         "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4),
-                                     "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)}},
-            "cpu_baseline": cpu,
-            "parity": parity,
-            "hbm_gbs_whole_job": round(world * bytes_per_step * args.steps / elapsed / 1e9, 1),
-            "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
-        }
-        print(json.dumps(line), flush=True)
-
+        roofline = {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>", "achieved": round(achieved, 1) if achieved else None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                    "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_step,
+                    "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
+                    # hand-over of filter state between the frames of a stream: share of units that had to
+                    # wait for their predecessor and the average wait of those (one poll ~ 1 us)
+                    "handoff": handoff}
+    else:
+        tops = flops_per_sample(1) * samples_per_step / (casc_avg * 1e-3) / 1e12 if casc_avg > 0 else None
+        roofline = {"bound": "fp64_valu", "kernel": "nvx_fir_cascade<252k,1>", "achieved": round(tops, 2) if tops else None,
+                    "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
+                    "traffic": None, "flop_per_sample": round(flops_per_sample(1), 2), "samples_per_launch": samples_per_step,
+                    "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
+                    "hbm_gbs": round(bytes_per_step / (casc_avg * 1e-3) / 1e9, 1) if casc_avg > 0 else None, "handoff": handoff,
+                    "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes"}
+    line = {
+        "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(value, 1), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, "
+                                f"{F} frames ({F * 0.32:.2f} s) resident in HBM (BASELINE configs[3]; x{world} GPUs = configs[4] shape)") if raw else
+                               (f"VARIANT A (not the headline): {S} channels x 252 kS/s int16 IQ per GPU, {F} frames ({F * 0.32:.2f} s), "
+                                f"no stage 0 -- fp64-issue-bound by design (SURVEY 7-2)"),
+                   "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step,
+                   "stage0": "integrate-and-dump /8 (build-owned)" if raw else "none", "chains_per_stream": 1,
+                   "parallelism": f"streams sharded {world} ways, no collective"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "parity": parity, "parity_streams_checked": checked_all, "parity_seconds": round(verify_s, 1),
+        "demod": {"near_ties": near_all, "min_relative_margin": margin_all, "timing_evaluations_rank0": int(evals)},
+        "host_threads": place["threads"], "placement": place,
+        "hbm_gbs_whole_job": round(world * bytes_per_step * args.steps / elapsed / 1e9, 1),
+        "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
+    }
     pipe.close()
     buf.free()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(line, parity, ranks, rank)
 
 
 if __name__ == "__main__":

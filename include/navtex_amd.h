@@ -153,6 +153,8 @@ typedef struct nvx_config {
                               /* (k = sub-band, centre k*252 kHz), so chain_masks / labels have   */
                               /* 8*n_streams entries.                                             */
     int      bit_history;     /* decoded bits kept per chain for nvx_poll_bits (0 = NVX_BIT_HISTORY) */
+    int      host_threads;    /* threads the character layer of one collect may use (0 = NVX_HOST_THREADS or   */
+                              /* the hardware's count, at most 16)                                             */
 } nvx_config;
 
 /* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the
@@ -209,6 +211,14 @@ NVX_API int   nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, ui
 /* hand-over statistics of the FIR-cascade work queue over the collected launches: how many units had to
  * wait for the previous frame of their stream, and how many polls (about 1 us each) they spent waiting  */
 NVX_API int   nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *units_waited, uint64_t *launches, int reset);
+/* How close the demodulator's bit-timing decisions came to a tie since create / reset.  The arg-max over the nine
+ * class sums (receiver/decoder.C:202-215, strict '>') is the one decision of the path that rests on delta-phi values
+ * which may differ from glibc's atan2 in the last bit; such a difference can only matter where the best sum and the
+ * runner-up are closer than ~1e-15 relative.  near_ties counts timing evaluations with best > 0 and a margin below
+ * 2^-40 relative (that is 4000 times wider than the last bit reaches); evaluations counts those with best > 0;
+ * min_margin is the smallest (best - runner_up) / best seen (-1 when there was no evaluation).  Synchronises with
+ * the handle's last launch.                                                                                      */
+NVX_API int   nvx_demod_tie_stats(nvx_handle *h, uint64_t *near_ties, uint64_t *evaluations, double *min_margin);
 /* self-test of the demodulator's bit-period transition table against the per-sample rule it is
  * generated from (receiver/decoder.C:62-137, 202-249), on `periods` pseudo-random bit periods;
  * returns the number of differences (0 = pass).  Host only, no device needed.                  */
@@ -228,6 +238,46 @@ NVX_API void  nvx_device_free(int device, void *p);
 NVX_API int   nvx_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
 NVX_API int   nvx_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
 NVX_API int   nvx_device_sync(int device);
+/* a hipStream_t of the caller's own (for nvx_process_resident's hip_stream argument), and its release          */
+NVX_API void *nvx_stream_create(int device);
+NVX_API void  nvx_stream_destroy(int device, void *hip_stream);
+
+/* ==========================================================================
+ * C'. Several GPUs behind one object.  NAVTEX chains share no state (receiver/decoder.h:31-60,
+ *    receiver/nav_b_sm.h:92-114; FIR1 + mixer state per stream: receiver/fir1cpp.C:57-60, receiver/fir2cpp.C:74-83),
+ *    so streams shard one contiguous subset per device and nothing is exchanged between devices: no collective.
+ *    A group owns one handle and one host thread per member; global stream id g lives on member m with
+ *    first(m) <= g < first(m) + count(m), first(m) = m * (S / n) + min(m, S % n).  The two chains of a stream stay
+ *    together (they share FIR1).  cfg is read as for nvx_create with n_streams = the TOTAL S; chain_masks / labels
+ *    are indexed by global stream; cfg.device is ignored; on_message receives the GLOBAL stream id.  Messages are
+ *    delivered by the thread that calls nvx_group_fetch_bits / nvx_group_flush, member after member, stream after
+ *    stream -- the same order one handle of S streams would use.  Two members may name the same device.
+ * ========================================================================== */
+typedef struct nvx_group nvx_group;
+NVX_API int    nvx_group_create(const int *devices, int n_members, const nvx_config *cfg, nvx_group **out);
+NVX_API void   nvx_group_destroy(nvx_group *g);
+NVX_API int    nvx_group_reset(nvx_group *g);
+NVX_API int    nvx_group_size(const nvx_group *g);
+/* member m: its device, first global stream, stream count and handle (any of the out pointers may be NULL)   */
+NVX_API int    nvx_group_member(nvx_group *g, int m, int *device, int *first_stream, int *n_streams, nvx_handle **h);
+/* global stream id -> member index (or -1)                                                                   */
+NVX_API int    nvx_group_member_of(const nvx_group *g, int global_stream);
+/* device-resident input: d_iq[m] is member m's buffer ON ITS DEVICE, layout [count(m)][pitch] as for
+ * nvx_process_resident.  The launches are issued by the members' own threads, all devices at once; returns
+ * after they have been QUEUED.  Errors surface at the next fetch.                                             */
+NVX_API int    nvx_group_process_resident(nvx_group *g, const void *const *d_iq, size_t pitch_samples,
+                                          size_t first_frame, int n_frames);
+/* wait for every member, run the character layers (in parallel, one member per thread), deliver messages      */
+NVX_API int    nvx_group_fetch_bits(nvx_group *g);
+/* host input by global stream id (nvx_push_iq of the owning member; cfg.push_mode) and the matching flush     */
+NVX_API int    nvx_group_push_iq(nvx_group *g, int global_stream, const int16_t *iq_interleaved, size_t n);
+NVX_API int    nvx_group_flush(nvx_group *g);
+NVX_API size_t nvx_group_poll_bits(nvx_group *g, int global_stream, int chain, char *out, size_t cap);
+NVX_API size_t nvx_group_bit_count(nvx_group *g, int global_stream, int chain);
+/* Bind the CALLING thread to the CPUs of the NUMA node the HIP device hangs off (PCI bus id -> sysfs numa_node /
+ * local_cpulist).  Returns the number of CPUs bound to, 0 when the platform gives no answer (affinity unchanged),
+ * or a negative error.  The group calls it for its member threads unless NVX_GROUP_NUMA=0.                     */
+NVX_API int    nvx_bind_thread_to_device(int device);
 
 /* ==========================================================================
  * D. Host SITOR-B / CCIR-476 character layer

@@ -16,7 +16,7 @@ from . import _native as N
 from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRAME_Y3, RATE_IN, RATE_RAW,
                       NvxError, lib)
 
-__all__ = ["Pipeline", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
+__all__ = ["Pipeline", "Group", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
            "DeviceBuffer", "channelise", "channelise_time_stats", "Store", "wav_write", "wav_read", "NvxError", "lib",
            "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
 
@@ -232,6 +232,12 @@ class Pipeline:
         N.check(lib.nvx_cascade_wait_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_wait_stats")
         return a.value, b.value, c.value
 
+    def tie_stats(self) -> Tuple[int, int, float]:
+        """(near ties, evaluations, smallest relative margin) of the bit-timing arg-max since create / reset."""
+        a, b, m = C.c_uint64(), C.c_uint64(), C.c_double()
+        N.check(lib.nvx_demod_tie_stats(self._h, C.byref(a), C.byref(b), C.byref(m)), "nvx_demod_tie_stats")
+        return a.value, b.value, m.value
+
     def enable_timing(self, on: bool = True) -> None:
         lib.nvx_enable_timing(self._h, int(on))
 
@@ -261,6 +267,90 @@ class Pipeline:
         if getattr(self, "_h", None):
             lib.nvx_destroy(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+class Group:
+    """nvx_group wrapper: n_streams sharded over `devices` (one handle + host thread per member, no collective)."""
+
+    def __init__(self, devices: Sequence[int], n_streams: int, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
+                 chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None, max_frames: int = 1,
+                 char_layer: bool = True, push_mode: bool = False, host_threads: int = 0):
+        self.messages: List[Tuple[int, int, str, str]] = []          # (global stream, freq, bbbb, text)
+        cfg = N.Config()
+        lib.nvx_config_default(C.byref(cfg))
+        cfg.n_streams, cfg.raw_rate, cfg.chain_mask = n_streams, int(raw_rate), chain_mask
+        cfg.max_frames, cfg.char_layer, cfg.push_mode, cfg.host_threads = max_frames, int(char_layer), int(push_mode), host_threads
+        if chain_masks is not None:
+            chain_masks = list(chain_masks)
+            self._masks = (C.c_uint8 * len(chain_masks))(*chain_masks)
+            cfg.chain_masks = self._masks
+        if labels is not None:
+            flat = [int(v) for pair in labels for v in pair]
+            self._labels = (C.c_int * len(flat))(*flat)
+            cfg.labels = self._labels
+        self._cb = N.MESSAGE_FN(lambda u, s, b, m, f: self.messages.append((s, f, b.decode("latin1"), m.decode("latin1"))))
+        cfg.on_message = self._cb
+        devs = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        N.check(lib.nvx_group_create(devs, len(devices), C.byref(cfg), C.byref(g)), "nvx_group_create")
+        self._g = g
+        self.n_streams = n_streams
+        self.members = []                                            # (device, first stream, stream count)
+        for m in range(lib.nvx_group_size(g)):
+            d, f, n = C.c_int(), C.c_int(), C.c_int()
+            N.check(lib.nvx_group_member(g, m, C.byref(d), C.byref(f), C.byref(n), None), "nvx_group_member")
+            self.members.append((d.value, f.value, n.value))
+        self._bits = {}
+
+    def member_of(self, stream: int) -> int:
+        return lib.nvx_group_member_of(self._g, stream)
+
+    def process_resident(self, ptrs: Sequence[int], pitch: int, first_frame: int, n_frames: int) -> None:
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        N.check(lib.nvx_group_process_resident(self._g, arr, pitch, first_frame, n_frames), "nvx_group_process_resident")
+
+    def fetch(self) -> None:
+        N.check(lib.nvx_group_fetch_bits(self._g), "nvx_group_fetch_bits")
+
+    def push(self, stream: int, iq: np.ndarray) -> None:
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1, 2)
+        N.check(lib.nvx_group_push_iq(self._g, stream, N.as_ptr(iq), iq.shape[0]), "nvx_group_push_iq")
+
+    def flush(self) -> None:
+        N.check(lib.nvx_group_flush(self._g), "nvx_group_flush")
+
+    def reset(self) -> None:
+        N.check(lib.nvx_group_reset(self._g), "nvx_group_reset")
+        self._bits.clear(); self.messages.clear()
+
+    def bits(self, stream: int, chain: int = 0) -> str:
+        cap = 1 << 16
+        buf = C.create_string_buffer(cap)
+        acc = self._bits.get((stream, chain), "")
+        while True:
+            n = lib.nvx_group_poll_bits(self._g, stream, chain, buf, cap)
+            acc += buf.raw[:n].decode("ascii")
+            if n < cap:
+                break
+        self._bits[(stream, chain)] = acc
+        return acc
+
+    def bit_count(self, stream: int, chain: int = 0) -> int:
+        return lib.nvx_group_bit_count(self._g, stream, chain)
+
+    def close(self) -> None:
+        if getattr(self, "_g", None):
+            lib.nvx_group_destroy(self._g)
+            self._g = None
 
     def __enter__(self):
         return self

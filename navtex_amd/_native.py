@@ -31,6 +31,7 @@ class Config(C.Structure):
         ("char_layer", C.c_int), ("on_message", MESSAGE_FN), ("user", C.c_void_p), ("push_mode", C.c_int),
         ("wideband", C.c_int),
         ("bit_history", C.c_int),
+        ("host_threads", C.c_int),
     ]
 
 
@@ -68,10 +69,20 @@ def _load() -> C.CDLL:
         "nvx_process_resident": (i, [vp, vp, sz, sz, i, vp]), "nvx_fetch_bits": (i, [vp]),
         "nvx_bit_count": (sz, [vp, i, i]),
         "nvx_last_kernel_ms": (C.c_float, [vp, i]), "nvx_enable_timing": (None, [vp, i]), "nvx_enable_debug": (i, [vp, i]),
+        "nvx_group_create": (i, [C.POINTER(C.c_int), i, C.POINTER(Config), C.POINTER(vp)]), "nvx_group_destroy": (None, [vp]),
+        "nvx_group_reset": (i, [vp]), "nvx_group_size": (i, [vp]),
+        "nvx_group_member": (i, [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(vp)]), "nvx_group_member_of": (i, [vp, i]),
+        "nvx_group_process_resident": (i, [vp, C.POINTER(vp), sz, sz, i]), "nvx_group_fetch_bits": (i, [vp]),
+        "nvx_group_push_iq": (i, [vp, i, vp, sz]), "nvx_group_flush": (i, [vp]),
+        "nvx_group_poll_bits": (sz, [vp, i, i, C.c_char_p, sz]), "nvx_group_bit_count": (sz, [vp, i, i]),
+        "nvx_bind_thread_to_device": (i, [i]),
+        "nvx_demod_tie_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+        "nvx_capture_error": (i, [vp, C.POINTER(C.c_uint64)]),
         "nvx_kernel_time_stats": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]),
         "nvx_debug_y3": (sz, [vp, i, i, vp, sz]), "nvx_debug_dphi": (sz, [vp, i, i, vp, sz]),
         "nvx_device_count": (i, []), "nvx_device_alloc": (vp, [i, sz]), "nvx_device_free": (None, [i, vp]),
         "nvx_memcpy_h2d": (i, [i, vp, vp, sz]), "nvx_memcpy_d2h": (i, [i, vp, vp, sz]), "nvx_device_sync": (i, [i]),
+        "nvx_stream_create": (vp, [i]), "nvx_stream_destroy": (None, [i, vp]),
         "nvx_sitor_new": (vp, [i, SITOR_MSG_FN, vp]), "nvx_sitor_set_trace": (None, [vp, SITOR_TRACE_FN, vp]),
         "nvx_sitor_free": (None, [vp]), "nvx_sitor_reset": (None, [vp]),
         "nvx_sitor_receive_bit": (None, [vp, C.c_char]), "nvx_sitor_receive_bits": (None, [vp, C.c_char_p, sz]),

@@ -25,7 +25,7 @@ ARCH = "gfx950"
 
 C_SOURCES = ["nvx_sitor.c", "nvx_wav.c", "nvx_synth_host.c", "nvx_store.c"]
 HIP_SOURCES = ["nvx_cascade.hip", "nvx_demod.hip", "nvx_channelise.hip", "nvx_synth.hip"]
-CXX_SOURCES = ["nvx_api.cpp", "nvx_push.cpp", "nvx_shim.cpp", "nvx_capture.cpp", "nvx_wideband.cpp", "nvx_synth_dev.cpp", "nvx_fsm_host.cpp"]
+CXX_SOURCES = ["nvx_api.cpp", "nvx_push.cpp", "nvx_shim.cpp", "nvx_capture.cpp", "nvx_wideband.cpp", "nvx_synth_dev.cpp", "nvx_fsm_host.cpp", "nvx_group.cpp"]
 
 # -ffp-contract=off is part of the numerical contract: FIR products and sums are
 # rounded separately, exactly as the reference's x86-64 build does.
@@ -77,7 +77,10 @@ def build_lib(force: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(_run, jobs))
     if force or _stale(LIB, objs):
-        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB, "-lpthread", "-ldl"])
+        # link beside the target and rename: another process (a second rank, a test runner) never maps a half-written file
+        tmp = LIB.with_name(LIB.name + f".tmp{os.getpid()}")
+        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lpthread", "-ldl"])
+        os.replace(tmp, LIB)
     return LIB
 
 

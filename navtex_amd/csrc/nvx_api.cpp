@@ -76,6 +76,7 @@ static void free_handle(nvx_handle *h)
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
     if (h->launch_done) hipEventDestroy(h->launch_done);
+    hipFree(h->d_ties); if (h->h_ties) hipHostFree(h->h_ties);
     hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
@@ -167,6 +168,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_fsm_tab, nvx_fsm_table_host(), NVX_FSM_TABLE_ALLOC * sizeof(uint32_t), hipMemcpyHostToDevice));
     CR_TRY(hipMalloc(&h->d_words, (size_t)(h->y3_cap / 9) * h->n_slots * sizeof(unsigned short)));
     CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
+    CR_TRY(hipMalloc(&h->d_ties, sizeof(nvx_tie_stats)));
+    CR_TRY(hipHostMalloc((void **)&h->h_ties, sizeof(nvx_tie_stats), hipHostMallocDefault));
     CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * 3 * sizeof(int), hipHostMallocDefault));
     memset(h->h_status, 0, RESULT_SLOTS * 3 * sizeof(int));
     for (auto &r : h->res) {
@@ -233,6 +236,9 @@ extern "C" int nvx_reset(nvx_handle *h)
         ints[(size_t)NVX_DI_PHASE * h->n_slots + i] = -1;
     }
     HIP_TRY(hipMemcpyAsync(h->d_di, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const nvx_tie_stats ties0 = { 0, 0, 0x7f800000u, 0 };
+    *h->h_ties = ties0;
+    HIP_TRY(hipMemcpyAsync(h->d_ties, &ties0, sizeof ties0, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto &s : h->slots) { s.bits.clear(); s.base = 0; s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
     if (!h->fill.empty()) std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
@@ -298,7 +304,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
     da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
-    da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi;
+    da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi; da.ties = h->d_ties;
 
     // cascade on `st`: it may not overwrite y3[yb] before the demodulator of two launches ago has read it
     if (h->demod_pending[yb]) HIP_TRY(hipStreamWaitEvent(st, h->demod_done[yb], 0));
@@ -323,6 +329,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[5], s2));
     HIP_TRY(hipEventRecord(h->fsm_done, s2));
     h->fsm_pending = true;
+    HIP_TRY(hipMemcpyAsync(h->h_ties, h->d_ties, sizeof(nvx_tie_stats), hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, s2));
     HIP_TRY(hipEventRecord(r.done, s2));
@@ -375,11 +382,14 @@ int nvx_collect_locked(nvx_handle *h)
                     }
                 }
             };
-            static const int host_threads = [] {
+            // cfg.host_threads, else NVX_HOST_THREADS, else the hardware's count; never more than 16 (7 ns per bit: more
+            // threads only add start-up cost).  A group (nvx_group.cpp) gives every member its share of the cores.
+            static const int env_threads = [] {
                 const char *e = getenv("NVX_HOST_THREADS");
                 int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
                 return n < 1 ? 1 : (n > 16 ? 16 : n);
             }();
+            const int host_threads = h->cfg.host_threads > 0 ? std::min(h->cfg.host_threads, 16) : env_threads;
             const int nt = (h->n_slots >= 256 && h->cfg.char_layer) ? host_threads : 1;
             if (nt > 1) {
                 std::vector<std::thread> pool;
@@ -472,6 +482,21 @@ extern "C" int nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *
     return NVX_OK;
 }
 
+extern "C" int nvx_demod_tie_stats(nvx_handle *h, uint64_t *near_ties, uint64_t *evaluations, double *min_margin)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));     // the pinned copy is refreshed behind every launch
+    if (near_ties) *near_ties = h->h_ties->near_ties;
+    if (evaluations) *evaluations = h->h_ties->evaluations;
+    if (min_margin) {
+        float f; memcpy(&f, &h->h_ties->min_margin_bits, sizeof f);
+        *min_margin = h->h_ties->evaluations ? (double)f : -1.0;
+    }
+    return NVX_OK;
+}
+
 extern "C" int nvx_enable_debug(nvx_handle *h, int enabled)
 {
     if (!h) return NVX_ERR_ARG;
@@ -531,4 +556,16 @@ extern "C" int nvx_device_sync(int device)
 {
     int rc = nvx_select_device(device); if (rc != NVX_OK) return rc;
     HIP_TRY(hipDeviceSynchronize()); return NVX_OK;
+}
+extern "C" void *nvx_stream_create(int device)
+{
+    if (nvx_select_device(device) != NVX_OK) return nullptr;
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { nvx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return nullptr; }
+    return (void *)s;
+}
+extern "C" void nvx_stream_destroy(int device, void *hip_stream)
+{
+    if (hip_stream && nvx_select_device(device) == NVX_OK) { hipStreamSynchronize((hipStream_t)hip_stream); hipStreamDestroy((hipStream_t)hip_stream); }
 }

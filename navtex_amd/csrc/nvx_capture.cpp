@@ -15,6 +15,7 @@ struct nvx_capture {
     std::mutex cv_mu; std::condition_variable cv;
     std::atomic<bool> stop{ false }, paused{ false };
     std::atomic<int> error{ NVX_OK };
+    int stalled = 0;                            // consumer only: consecutive back-pressure rounds in which nothing was taken
     std::mutex rec_mu; nvx_wav *rec = nullptr;  // debug recording of what the consumer hands on (capt_sched.c:87-101, 516)
     std::thread worker;
 };
@@ -31,6 +32,7 @@ static void capture_consumer(nvx_capture *c)
         if (c->paused.load() && !c->stop.load()) continue;
         uint64_t t = c->tail.load(), hd = c->head.load();
         bool backoff = false;
+        const uint64_t t_in = t;
         while (t != hd && !(c->paused.load() && !c->stop.load())) {      // contiguous spans, wrap split as capt_sched.c:494-503
             size_t at = (size_t)(t % c->cap);
             size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
@@ -38,7 +40,7 @@ static void capture_consumer(nvx_capture *c)
             int rc = nvx_push_iq_partial(c->h, c->stream, c->ring.data() + 2 * at, n, &took);
             // Another stream of the handle is a whole staging set behind (its radio stalled): back-pressure, not an
             // error.  Keep what was not taken in the ring (its overrun accounting counts any loss) and retry after the
-            // poll interval; while stopping there is nobody left to catch up, so the rest is given up.
+            // poll interval.  While stopping, a handle that takes nothing for a second is given up on (NVX_ERR_FULL).
             if (rc == NVX_ERR_FULL) { c->full_waits.fetch_add(1); backoff = true; }
             else if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }      // hard error (HIP): give up, report
             n = took;
@@ -54,10 +56,12 @@ static void capture_consumer(nvx_capture *c)
             if (backoff) break;
         }
         if (backoff) {
-            if (c->stop.load()) { c->error.store(NVX_ERR_FULL); return; }
+            c->stalled = (c->tail.load() == t_in) ? c->stalled + 1 : 0;
+            if (c->stop.load() && c->stalled >= 20) { c->error.store(NVX_ERR_FULL); return; }
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
             continue;
         }
+        c->stalled = 0;
         if (c->stop.load() && c->head.load() == c->tail.load()) return;
     }
 }

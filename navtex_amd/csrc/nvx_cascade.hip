@@ -53,6 +53,7 @@
 //     just the three filter histories.#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "nvx_tables.h"
 #include "nvx_kernels.h"
@@ -633,24 +634,36 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 // ===========================================================================
 // launcher (C linkage, called from the host runtime)
 // ===========================================================================
-// tuning switches for A/B runs (defaults are the shipped configuration)
+#define NVX_MAX_DEVICES 64
+// tuning switches for A/B runs (defaults are the shipped configuration; read once per process)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 template <bool RAW, int NCH, int PFD, bool NT>
 static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
 {
-    // persistent grid: as many single-wave workgroups as the chip holds at once
-    static int n_cus = 0, fit_per_cu = 0;
-    if (!n_cus) {
-        int dev = 0, cus = 0, per_cu = 0;
+    // persistent grid: as many single-wave workgroups as the device of this launch holds at once (cached per device:
+    // handles on different devices, and launches from different threads, share this function)
+    static std::mutex mu;
+    static int cus_of[NVX_MAX_DEVICES], fit_of[NVX_MAX_DEVICES];
+    int n_cus = 0, fit_per_cu = 0;
+    {
+        int dev = 0;
         hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nvx_fir_cascade<RAW, NCH, PFD, NT>, 64, 0);
         if (e != hipSuccess) return e;
-        const int cap = env_int("NVX_WAVES_PER_CU", 0);
-        if (cap > 0 && cap < per_cu) per_cu = cap;
-        fit_per_cu = per_cu > 0 ? per_cu : 1;
-        n_cus = cus;
+        std::lock_guard<std::mutex> lk(mu);
+        const bool cached = dev >= 0 && dev < NVX_MAX_DEVICES && cus_of[dev] > 0;
+        if (!cached) {
+            int cus = 0, per_cu = 0;
+            e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nvx_fir_cascade<RAW, NCH, PFD, NT>, 64, 0);
+            if (e != hipSuccess) return e;
+            const int cap = env_int("NVX_WAVES_PER_CU", 0);
+            if (cap > 0 && cap < per_cu) per_cu = cap;
+            n_cus = cus; fit_per_cu = per_cu > 0 ? per_cu : 1;
+            if (dev >= 0 && dev < NVX_MAX_DEVICES) { cus_of[dev] = n_cus; fit_of[dev] = fit_per_cu; }
+        } else {
+            n_cus = cus_of[dev]; fit_per_cu = fit_of[dev];
+        }
     }
     int per_cu = fit_per_cu;
     if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;

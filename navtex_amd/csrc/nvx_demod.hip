@@ -75,8 +75,12 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_a
     __shared__ double s_S[8 + DTL];
     __shared__ double s_C[567 + DTL];
     __shared__ unsigned char s_D[DTL];
+    __shared__ unsigned s_near, s_evals, s_minm;
     const int slot = blockIdx.x, tid = threadIdx.x;
     if (!a.slot_active[slot]) return;                    // uniform over the block
+    if (tid == 0) { s_near = 0; s_evals = 0; s_minm = 0x7f800000u; }
+    unsigned my_near = 0, my_evals = 0;
+    float my_minm = __uint_as_float(0x7f800000u);
 
     double *st = a.dstate + (size_t)slot * NVX_DEMOD_DOUBLES;
     const double2 *y3 = a.y3 + (size_t)slot * a.y3_cap + a.y3_base;
@@ -165,12 +169,20 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_a
             const int L = 9 * M + (G_CSA % 9);
             unsigned max_index = 15;
             if (gt + L >= G_CSA) {
-                double temp_max = -1.0;
+                double temp_max = -1.0, runner_up = -1.0;
                 max_index = 0;
 #pragma unroll
                 for (int i = 0; i < 9; i++) {
                     const double v = s_S[L + i];
-                    if (v > temp_max) { temp_max = v; max_index = i; }
+                    if (v > temp_max) { runner_up = temp_max; temp_max = v; max_index = i; }
+                    else if (v > runner_up) runner_up = v;
+                }
+                // instrumentation only (nvx_tie_stats): how close was that decision?
+                if (temp_max > 0.0) {
+                    const double margin = temp_max - runner_up;
+                    my_evals++;
+                    if (margin < temp_max * 0x1p-40) my_near++;
+                    my_minm = fminf(my_minm, (float)(margin / temp_max));
                 }
             }
             a.words[(size_t)slot * (a.y3_cap / 9) + (ta / 9 + M)] = (unsigned short)(w | (max_index << 12));
@@ -188,6 +200,13 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_a
         __syncthreads();
     }
 
+    if (my_evals) { atomicAdd(&s_near, my_near); atomicAdd(&s_evals, my_evals); atomicMin(&s_minm, __float_as_uint(my_minm)); }
+    __syncthreads();
+    if (tid == 0 && s_evals) {
+        if (s_near) atomicAdd(&a.ties->near_ties, (unsigned long long)s_near);
+        atomicAdd(&a.ties->evaluations, (unsigned long long)s_evals);
+        atomicMin(&a.ties->min_margin_bits, s_minm);
+    }
     if (tid < 4 && a.n3 >= 4) { const double2 l = y3[a.n3 - 4 + tid]; st[DS_Y3 + 2 * tid] = l.x; st[DS_Y3 + 2 * tid + 1] = l.y; }
     if (tid < 8) { st[DS_DPHI + tid] = s_dphi[tid]; st[DS_S + tid] = s_S[tid]; }
     for (int i = tid; i < 567; i += NVX_FRONT_THREADS) st[DS_C + i] = s_C[i];

@@ -91,6 +91,8 @@ struct nvx_handle {
     double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
     uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
     unsigned short *d_words = nullptr;
+    nvx_tie_stats *d_ties = nullptr;   // arg-max margin statistics, cumulative since create / reset
+    nvx_tie_stats *h_ties = nullptr;   // pinned copy, refreshed behind every launch
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
     int *h_status = nullptr;           // pinned copies of {status, wait polls, units that waited} per result slot
     uint64_t wait_polls = 0, wait_units = 0, wait_launches = 0;   // accumulated at collect

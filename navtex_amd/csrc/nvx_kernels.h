@@ -59,6 +59,17 @@ typedef struct {
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid      */
 } nvx_cascade_args;
 
+/* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares
+ * are built from delta-phi values that may differ from glibc's atan2 in the last bit; such a difference
+ * moves a sum by ~1e-16 relative, so it can only change the decision where best and runner-up are closer than that.
+ * A timing evaluation counts as a NEAR TIE when best > 0 and (best - runner_up) < best * 2^-40.                          */
+typedef struct {
+    unsigned long long near_ties;      /* evaluations with a margin below 2^-40 relative                               */
+    unsigned long long evaluations;    /* evaluations with best > 0 (silence -- all sums exactly 0 -- has no margin)    */
+    unsigned int min_margin_bits;      /* smallest (best - runner_up) / best seen, as float bits (0x7f800000 = none yet) */
+    unsigned int pad;
+} nvx_tie_stats;
+
 typedef struct {
     const double2 *y3;
     size_t y3_cap, y3_base;
@@ -72,6 +83,7 @@ typedef struct {
     unsigned short *words;     /* [n_slots][y3_cap/9] per-bit-period hand-over, front -> fsm (rows 16-byte aligned) */
     uint8_t *bits; int bits_cap; int *nbits;   /* bits: packed, B = 1, LSB first; bits_cap bytes (multiple of 4) per slot */
     double *dphi;              /* optional debug tap, same layout as y3 (or NULL)      */
+    nvx_tie_stats *ties;       /* cumulative arg-max margin statistics (never NULL)    */
 } nvx_demod_args;
 
 typedef struct {

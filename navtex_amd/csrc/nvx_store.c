@@ -127,7 +127,11 @@ int nvx_store_open(const char *path, int create_schema, nvx_store **out)
     if (!path || !*path || !out) { nvx_set_error("nvx_store_open: bad argument"); return NVX_ERR_ARG; }
     *out = NULL;
     pthread_once(&sq_once, sq_bind);
-    if (!sq_ok) { nvx_set_error("nvx_store_open: libsqlite3.so.0 not found (%s)", dlerror() ? dlerror() : "missing symbol"); return NVX_ERR_IO; }
+    if (!sq_ok) {
+        const char *why = dlerror();              /* dlerror() clears its message: read it once */
+        nvx_set_error("nvx_store_open: libsqlite3.so.0 not found (%s)", why ? why : "missing symbol");
+        return NVX_ERR_IO;
+    }
     nvx_store *s = (nvx_store *)calloc(1, sizeof *s);
     if (!s) return NVX_ERR_NOMEM;
     s->path = strdup(path);

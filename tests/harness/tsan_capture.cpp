@@ -33,6 +33,17 @@ extern "C" int nvx_push_iq(nvx_handle *, int, const int16_t *iq, size_t n)
     g_pushed += n;
     return NVX_OK;
 }
+// what the consumer really calls: now and then the "handle" is full (another stream of it stalled) and takes only part
+// of the span -- back-pressure the consumer must absorb without losing or repeating a sample
+static unsigned g_calls = 0;
+int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted)
+{
+    const bool full = (++g_calls % 7) == 0;
+    const size_t take = full ? n / 3 : n;
+    nvx_push_iq(h, stream, iq, take);
+    *accepted = take;
+    return full ? NVX_ERR_FULL : NVX_OK;
+}
 extern "C" int nvx_flush(nvx_handle *) { return NVX_OK; }
 
 int main(int argc, char **argv)
@@ -72,10 +83,13 @@ int main(int argc, char **argv)
     vendor.join(); meddler.join();
     uint64_t rx, dropped, used;
     nvx_capture_stats(cap, &rx, &dropped, &used);
+    uint64_t full_waits = 0;
+    if (nvx_capture_error(cap, &full_waits) != NVX_OK) return 6;       // back-pressure is not an error
     if (nvx_capture_stop(cap) != NVX_OK) return 4;
     const uint64_t pushed = g_pushed.load();
-    printf("received %llu dropped %llu pushed %llu bad %llu\n", (unsigned long long)rx, (unsigned long long)dropped,
-           (unsigned long long)pushed, (unsigned long long)g_bad.load());
+    printf("received %llu dropped %llu pushed %llu bad %llu full_waits %llu\n", (unsigned long long)rx, (unsigned long long)dropped,
+           (unsigned long long)pushed, (unsigned long long)g_bad.load(), (unsigned long long)full_waits);
+    if (full_waits == 0) return 7;                                     // the back-pressure path really ran
     if (rx != total || pushed + dropped != total || g_bad.load() != 0) return 5;
     printf("tsan capture ok\n");
     return 0;

@@ -185,7 +185,8 @@ def test_long_run_state_carry(nv, oracle):
 def test_full_size_properties_config3(nv, oracle):
     """BASELINE configs[3] at full size (4096 streams x 2.016 MS/s, 12 frames = 127 GB in HBM), checked
     through size-independent properties: run-to-run determinism, identical streams decode identically,
-    a different launch partition changes nothing, and a sample of streams matches the oracle bit for bit."""
+    a different launch partition changes nothing, and a sample of streams matches the oracle bit for bit
+    (test_full_size_total_parity_config3 compares ALL of them)."""
     S, F = 4096, 12
     pitch = F * nv.FRAME_RAW
     try:
@@ -322,3 +323,129 @@ print(h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(out.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
+def _run_full_size_total(nv, oracle, S, F, ncpu):
+    """All S streams of a configs[3]-shaped batch against the oracle, bit for bit; returns (checked, bad, seconds, ties)."""
+    import fullsize
+    pitch = F * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(S * pitch * 4)
+    streams = [signals.stream_params(nv, s, nv.RATE_RAW)[0] for s in range(S)]
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F, char_layer=False) as p:
+        p.process_resident(buf, pitch, 0, F)
+        p.fetch()
+        checked, bad, secs = fullsize.verify_streams(oracle, buf, pitch, pitch, True, lambda s: p.bits(s, 0), range(S), ncpu)
+        ties = p.tie_stats()
+    buf.free()
+    return checked, bad, secs, ties
+
+
+def test_full_size_total_parity_config3(nv, oracle, tmp_path):
+    """BASELINE configs[3] at full size: EVERY one of the 4096 streams' bits equals the oracle's (the batch is copied back
+    in 64 chunks of 2 GB and decoded by the oracle with OpenMP) -- in the unit form the launcher picks at this size
+    (hand-over between the frames of a stream) and, in a second process, with independent units forced.  No bit-timing
+    decision of the whole batch is anywhere near a tie (nvx_demod_tie_stats)."""
+    import os, subprocess, sys, json
+    S, F = 4096, 12
+    ncpu = min(16, len(os.sched_getaffinity(0)))
+    try:
+        checked, bad, secs, ties = _run_full_size_total(nv, oracle, S, F, ncpu)
+    except nv.NvxError:
+        pytest.skip("not enough device memory for the full-size batch")
+    print(f"total parity: {checked} streams in {secs:.1f} s; ties {ties}")
+    assert checked == S and bad == [], f"{len(bad)} of {checked} streams differ from the oracle: {bad[:20]}"
+    near, evals, margin = ties
+    assert near == 0 and evals > S * 250 and margin > 2.0 ** -40
+    script = tmp_path / "indep.py"
+    script.write_text('''
+import sys, os, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import navtex_amd as nv, oracle_binding as ob, signals
+import test_gpu_parity as T
+checked, bad, secs, ties = T._run_full_size_total(nv, ob, 4096, 12, int(sys.argv[2]))
+print(json.dumps({"checked": checked, "bad": bad[:20], "n_bad": len(bad), "secs": secs, "ties": ties}))
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    out = subprocess.run([sys.executable, str(script), root, str(ncpu)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, NVX_INDEPENDENT="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["checked"] == S and rec["n_bad"] == 0, rec
+    assert rec["ties"][0] == 0
+
+
+def test_noise_only_has_no_near_tie(nv, oracle):
+    """The golden noise-only case (the worst case for near-ties: no signal dominates the class sums): bits equal the
+    compiled reference's, and the smallest relative margin of a timing decision is reported and far above 2^-40."""
+    import json, cases
+    gold = json.loads((Path(__file__).parent / "golden" / "golden.json").read_text())["iq"]["noise_only"]
+    iq = cases.make_iq(nv, gold["spec"])
+    n = (iq.shape[0] // nv.FRAME_IN) * nv.FRAME_IN
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True, char_layer=False) as p:
+        p.push(0, iq[:n]); p.flush()
+        b518, b490 = p.bits(0, 0), p.bits(0, 1)
+        near, evals, margin = p.tie_stats()
+    assert gold["bits518"].startswith(b518) and gold["bits490"].startswith(b490) and len(b518) > 400
+    print(f"noise only: {evals} timing evaluations, smallest relative margin {margin:.3e}")
+    assert near == 0 and evals > 800 and margin > 1e-9
+
+
+def test_three_carriers_resident_raw_rate_config2(nv, oracle):
+    """BASELINE configs[2] through the roofline kernel form: three carriers in two 2.016 MS/s streams resident in HBM --
+    stream 0 carries 518 (+14 kHz) and 490 (-14 kHz) with different texts, stream 1 the "4209.5 kHz" carrier at +14 kHz of
+    its own centre, decoded by a 518-type chain under the label 4209 (the reference knows only 518 / 490:
+    receiver/nav_sched.C:10-11).  Bits against the oracle, messages with their labels."""
+    F = 62                                                        # 19.8 s
+    n = F * nv.FRAME_RAW
+    spb = nv.RATE_RAW // 100
+    texts = {518: "ZCZC EA01\nTEST MESSAGE 123 OK\nNNNN\n", 490: "ZCZC GB42\nGALE WARNING 7/8 NW-LY.\nNNNN\n", 4209: "ZCZC QA07\nHF NAVTEX 4209.5\nNNNN\n"}
+    s0 = nv.make_stream([dict(freq_hz=14000, bits=nv.sitor_encode(texts[518], 40), bit_offset=6217 % spb, phase0=11, amplitude=7000),
+                         dict(freq_hz=-14000, bits=nv.sitor_encode(texts[490], 44), bit_offset=15991 % spb, phase0=22, amplitude=6000)], seed=3, noise_amp=1500)
+    s1 = nv.make_stream([dict(freq_hz=14000, bits=nv.sitor_encode(texts[4209], 42), bit_offset=9001 % spb, phase0=33, amplitude=8000)], seed=4, noise_amp=1500)
+    buf = nv.DeviceBuffer(2 * n * 4)
+    nv.synth_device([s0, s1], nv.RATE_RAW, n, buf, n)
+    with nv.Pipeline(n_streams=2, raw_rate=True, chain_masks=[3, 1], labels=[[518, 490], [4209, 0]], max_frames=16) as p:
+        f0 = 0
+        while f0 < F:
+            k = min(16, F - f0)
+            p.process_resident(buf, n, f0, k); f0 += k
+        p.fetch()
+        for s, st, mask in ((0, s0, 3), (1, s1, 1)):
+            ref = oracle.Pipe(chain_mask=mask, charlayer=False)
+            ref.push_raw(buf.download(n * 4, offset=s * n * 4, dtype=np.int16).reshape(-1, 2))
+            for c in range(2):
+                assert p.bits(s, c) == (ref.bits(c) if (mask >> c) & 1 else ""), f"stream {s} chain {c}"
+        got = sorted((s, f, b, m) for (s, f, b, m) in p.messages)
+        assert got == sorted([(0, 518, "EA01", texts[518]), (0, 490, "GB42", texts[490]), (1, 4209, "QA07", texts[4209])])
+    buf.free()
+
+
+def test_launches_on_different_streams_stay_ordered(nv, oracle):
+    """nvx_process_resident takes a caller stream per call; the carried state (work queue, FIR histories, demodulator
+    state) makes the launches of a handle sequential whatever streams they are given: calls alternate between two
+    caller streams and the handle's own, and the result is that of one stream."""
+    S, F = 40, 18
+    masks = [3 if s % 4 == 0 else 1 for s in range(S)]
+    pitch = F * nv.FRAME_IN
+    streams = [signals.stream_params(nv, 300 + s, nv.RATE_IN)[0] for s in range(S)]
+    buf = nv.DeviceBuffer(S * pitch * 4)
+    nv.synth_device(streams, nv.RATE_IN, pitch, buf, pitch)
+    sa, sb = nv.lib.nvx_stream_create(0), nv.lib.nvx_stream_create(0)
+    assert sa and sb and sa != sb
+    with nv.Pipeline(n_streams=S, raw_rate=False, chain_masks=masks, max_frames=2, char_layer=False) as p:
+        for rep in range(3):
+            p.reset()
+            f0, k = 0, 0
+            while f0 < F:
+                n = 1 + (k % 2)
+                n = min(n, F - f0)
+                hs = (sa, None, sb)[k % 3]
+                p.process_resident(buf, pitch, f0, n, hip_stream=hs); f0 += n; k += 1
+            p.fetch()
+            for s in range(0, S, 3):
+                ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
+                ref.push(nv.synth_host(streams[s], nv.RATE_IN, pitch))
+                assert p.bits(s, 0) == ref.bits(0), f"round {rep} stream {s}"
+    nv.lib.nvx_stream_destroy(0, sa); nv.lib.nvx_stream_destroy(0, sb)
+    buf.free()

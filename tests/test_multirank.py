@@ -74,6 +74,80 @@ def test_two_ranks_shard_streams_without_collective(tmp_path, nv, oracle):
     assert len(rec["bits"]) == 6
 
 
+RANKS_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+    import torch, torch.distributed as dist
+    import bench
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranks = bench.Ranks(torch, dist, None, "gloo")
+    ranks.sync()
+    # rank 1's shard "fails": the verdict of the job is the minimum over ranks, the count the sum, the time the maximum
+    ok = rank != 1
+    parity = ranks.reduce(1.0 if ok else 0.0, "min") > 0.5
+    checked = int(ranks.reduce(32.0, "sum"))
+    elapsed = ranks.reduce(1.0 + rank, "max")
+    line = {{"parity": parity, "parity_streams_checked": checked, "elapsed": elapsed}}
+    bench.finish(line, parity, ranks, rank)      # prints on rank 0, exits 3 on EVERY rank
+""")
+
+
+def test_every_rank_checks_itself_and_the_job_fails_when_one_does(tmp_path):
+    """bench.py's rank logic on gloo, world size 2: parity = MIN over ranks, streams checked = SUM, time = MAX; a rank
+    whose shard differs from the oracle fails the whole job (exit status 3 on every rank, line still printed)."""
+    import json
+    script = tmp_path / "ranks_worker.py"
+    script.write_text(RANKS_WORKER.format(root=str(ROOT)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec == {"parity": False, "parity_streams_checked": 64, "elapsed": 2.0}
+
+
+def test_host_placement_helpers():
+    """bench.py binds a rank to its GPU's NUMA node before any GPU call and sizes the host pools from its share of the
+    cores; on a box without GPUs (here) it must leave the affinity alone and still give a sane thread count."""
+    sys.path.insert(0, str(ROOT))
+    import bench, fullsize
+    before = os.sched_getaffinity(0)
+    assert bench._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    old = os.environ.pop("NVX_HOST_THREADS", None)
+    try:
+        place = bench.place_rank(0, 8, 0)
+        assert os.sched_getaffinity(0) <= before and 1 <= place["threads"] <= 16
+        assert os.environ["NVX_HOST_THREADS"] == str(place["threads"])
+    finally:
+        os.sched_setaffinity(0, before)
+        os.environ.pop("NVX_HOST_THREADS", None)
+        if old is not None:
+            os.environ["NVX_HOST_THREADS"] = old
+    assert fullsize.spread(4096, 32)[0] == 0 and fullsize.spread(4096, 32)[-1] == 4095 and len(fullsize.spread(4096, 32)) == 32
+    assert fullsize.spread(5, 32) == [0, 1, 2, 3, 4]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_run_the_hip_path_and_check_their_own_shards(tmp_path):
+    """The real bench.py with two processes (gloo for the three scalars it reduces; RCCL refuses two ranks on one
+    device), both on GPU 0, each with its own shard of global stream ids: every rank verifies 32 streams of ITS shard
+    against the oracle and the line carries the minimum."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", NVX_BENCH_BACKEND="gloo", NVX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2", "--streams", "96", "--frames", "6",
+                          "--steps", "2", "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["parity"] is True and rec["parity_streams_checked"] == 64
+    assert rec["demod"]["near_ties"] == 0 and rec["host_threads"] >= 1
+    assert rec["config"]["streams_per_gpu"] == 96 and rec["scaling"] == "weak"
+
+
 def test_bench_refuses_multi_gpu_without_launcher():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})

@@ -7,7 +7,7 @@ for round in 1 2; do for lib in "$@"; do
     if [ "$lib" = "-" ]; then unset NAVTEX_AMD_LIB; else export NAVTEX_AMD_LIB=$R/$lib; fi
     for mode in "" "--variant-a --frames 96 --steps 5" "--wideband 512 --frames 12"; do
         echo "== $lib | ${mode:-headline}" >> $L
-        timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu $mode 2>>$R/gpurun_out/ab3.err >> $L || { echo FAILED >> $L; tail -5 $L; tail -5 $R/gpurun_out/ab3.err; exit 1; }
+        timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu --verify 32 $mode 2>>$R/gpurun_out/ab3.err >> $L || { echo FAILED >> $L; tail -5 $L; tail -5 $R/gpurun_out/ab3.err; exit 1; }
     done
 done; done
 python - <<PY

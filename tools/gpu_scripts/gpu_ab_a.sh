@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out; L=$R/gpurun_out/ab_a.log; : > $L
 for round in 1 2; do for lib in "$@"; do
     if [ "$lib" = "-" ]; then unset NAVTEX_AMD_LIB; else export NAVTEX_AMD_LIB=$R/$lib; fi
     echo "== $lib" >> $L
-    timeout -k 10 300 python bench.py --warmup 2 --no-cpu $mode 2>>$R/gpurun_out/ab_a.err >> $L || { echo FAILED >> $L; tail -5 $L; tail -5 $R/gpurun_out/ab_a.err; }
+    timeout -k 10 300 python bench.py --warmup 2 --no-cpu --verify 32 $mode 2>>$R/gpurun_out/ab_a.err >> $L || { echo FAILED >> $L; tail -5 $L; tail -5 $R/gpurun_out/ab_a.err; }
 done; done
 python - <<PY
 import json

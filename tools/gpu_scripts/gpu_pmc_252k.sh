@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 cd $R
 run_one() {   # name, bench args
     local n=$1; shift
-    local B="python3 bench.py --no-cpu --steps 3 --warmup 1 $*"
-    timeout -k 10 300 python3 bench.py --no-cpu --steps 6 --warmup 1 "$@" > $O/${n}_bench.json 2> $O/${n}_bench.err || { echo "$n bench failed"; tail -5 $O/${n}_bench.err; return 1; }
+    local B="python3 bench.py --no-cpu --verify 32 --steps 3 --warmup 1 $*"
+    timeout -k 10 300 python3 bench.py --no-cpu --verify 32 --steps 6 --warmup 1 "$@" > $O/${n}_bench.json 2> $O/${n}_bench.err || { echo "$n bench failed"; tail -5 $O/${n}_bench.err; return 1; }
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${n}_kt -- $B > $O/${n}_kt.log 2>&1 || { echo "$n kernel-trace failed"; return 1; }
     cp $(find $O/${n}_kt -name '*kernel_stats.csv' | head -1) $O/${n}_stats.csv
     timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/${n}_p1 -- $B > $O/${n}_p1.log 2>&1 || { echo "$n p1 failed"; return 1; }
