@@ -269,6 +269,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     dem_ms, _ = pipe.kernel_time_stats(1)
     ch_ms, n_c = nv.channelise_time_stats()
     casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
+    fused = n_c == 0                                # the fused kernel has no separate channeliser launch
     sub_samples = 8 * W * n_sub
     tops = flops_per_sample(2) * sub_samples / (casc_avg * 1e-3) / 1e12 if casc_avg else None
     line = {
@@ -281,13 +282,17 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                    "parallelism": f"wideband streams sharded {world} ways, no collective"},
         "carriers_decoded": 16 * W * world,
         "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
-        "roofline": {"bound": "fp64_valu", "kernel": "nvx_fir_cascade<252k,2>", "achieved": round(tops, 2) if tops else None,
+        "roofline": {"bound": "fp64_valu", "kernel": "nvx_wideband_fused (channeliser + 8 x two-chain cascade)" if fused else "nvx_fir_cascade<252k,2>",
+                     "achieved": round(tops, 2) if tops else None,
                      "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
                      "traffic": None, "flop_per_sample": round(flops_per_sample(2), 2), "samples_per_launch": sub_samples,
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_avg_launch_ms": round(dem_ms / max(n_l, 1), 3),
-                     "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes"},
-        "channeliser": {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
+                     "algorithmic_bytes_per_launch": W * n_raw * 4,
+                     "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes; "
+                             "only the cascade's fp64 operations are counted, the channeliser's integer work rides on top"},
+        "channeliser": None if fused else {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
                         "read_plus_write_gbs": round((W * n_raw * 4 + sub_samples * 4) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
+        "form": "fused (one kernel, sub-bands stay in LDS)" if fused else "two kernels (NVX_WB_FUSED=0)",
         "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "demod": {"near_ties": near_ties},
         "host_threads": place["threads"], "placement": place, "gen_seconds": round(t_gen, 1),
     }

@@ -245,6 +245,12 @@ extern "C" int nvx_reset(nvx_handle *h)
     return NVX_OK;
 }
 
+bool nvx_wb_fused()
+{
+    static const bool fused = !(getenv("NVX_WB_FUSED") && atoi(getenv("NVX_WB_FUSED")) == 0);
+    return fused;
+}
+
 // launch cascade + demod over n_frames frames of [n_streams][pitch] packed IQ
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
                       bool input_on_stream3)
@@ -263,7 +269,11 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // 21.2 ms per step -- the capped cascade and the demodulator slow down by more than the 6 ms hidden.
     // Default: channeliser in front of the cascade on the same stream.  NVX_WB_OVERLAP=1 re-enables it.
     static const bool wb_overlap = getenv("NVX_WB_OVERLAP") && atoi(getenv("NVX_WB_OVERLAP")) == 1;
-    if (h->cfg.wideband) {
+    // Wideband handles run the fused kernel (nvx_wideband_fused.hip: the stream is read once, the sub-bands never
+    // leave the LDS).  NVX_WB_FUSED=0 selects the two-kernel form (channeliser -> sub-band buffer -> cascade): A/B runs.
+    const bool fused = h->cfg.wideband && nvx_wb_fused();
+    const void *d_wide = d_iq; const size_t wide_pitch = pitch, wide_first = first_sample;
+    if (h->cfg.wideband && !fused) {
         // channeliser into sub[wb]; sub[wb] was last read by the cascade two launches ago
         hipStream_t s3 = (wb_overlap || input_on_stream3) ? h->stream3 : st;
         // Input ordering.  Push path: the H2D copy was issued on stream3 itself.  Resident path on the
@@ -310,9 +320,21 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (h->demod_pending[yb]) HIP_TRY(hipStreamWaitEvent(st, h->demod_done[yb], 0));
     r.timed = h->timing;
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[0], st));
-    HIP_TRY(nvx_launch_cascade(&ca, h->cascade_raw, h->nch, st));
+    if (fused) {
+        nvx_wideband_args wa{};
+        wa.raw = (const uint32_t *)d_wide; wa.pitch = wide_pitch; wa.first_sample = wide_first;
+        wa.n_wide = h->n_in; wa.n_frames = n_frames; wa.chain_masks = h->d_masks;
+        wa.state_in = ca.state_in; wa.state_out = ca.state_out;
+        wa.hist_in = h->d_whist[wb]; wa.hist_out = h->d_whist[wb ^ 1];       // launch k reads [k & 1], writes the other
+        wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
+        wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done;
+        HIP_TRY(nvx_launch_wideband_fused(&wa, st));
+        h->wide_launches++;
+    } else {
+        HIP_TRY(nvx_launch_cascade(&ca, h->cascade_raw, h->nch, st));
+    }
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
-    if (h->cfg.wideband) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
+    if (h->cfg.wideband && !fused) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
     HIP_TRY(hipMemcpyAsync(h->h_status + 3 * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
     // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads

@@ -16,19 +16,8 @@
 //   out_k = clamp16((Y[k] + 4096) >> 13)
 // Mapping: one wave per span of one wideband stream; a chunk = 64 output instants =
 // 512 raw samples (2 KiB in, 8 x 256 B out).  The 48-sample window of lane m is
-// LDS words 8m .. 8m+47 (twelve ds_read_b128); the branch sums use v_dot2_i32_i16
-// with (h, 0) / (0, h) selector constants, so no sign extension is needed.
-#define NVX_PFB_TABLE static constexpr
-#include "nvx_pfb_taps.h"
-
-__device__ __forceinline__ int mulc45(int t) { return (int)(((long long)t * NVX_PFB_C45) >> 15); }
-__device__ __forceinline__ unsigned pack_clamp16(int re, int im)
-{
-    re = (re + 4096) >> 13; im = (im + 4096) >> 13;
-    re = re > 32767 ? 32767 : (re < -32768 ? -32768 : re);
-    im = im > 32767 ? 32767 : (im < -32768 ? -32768 : im);
-    return ((unsigned)re & 0xffffu) | ((unsigned)im << 16);
-}
+// LDS words 8m .. 8m+47; the arithmetic of one instant is nvx_pfb.h.
+#include "nvx_pfb.h"
 
 __global__ __launch_bounds__(64) void nvx_channelise(nvx_channelise_args a)
 {
@@ -55,39 +44,11 @@ __global__ __launch_bounds__(64) void nvx_channelise(nvx_channelise_args a)
         *(u32x4 *)&win[40 + 256 + 4 * lane] = v1;
         NVX_WAVE_LDS_FENCE();
 
-        int ur[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ui[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int r = 0; r < 12; r++) {
-            const u32x4 w = *(const u32x4 *)&win[8 * lane + 4 * r];
-            const unsigned ww[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int j = 4 * r + e;
-                const int h = NVX_PFB_H[47 - j];
-                const nvx_short2 hI = { (short)h, 0 }, hQ = { 0, (short)h };
-                ur[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), hI, ur[j & 7], false);
-                ui[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), hQ, ui[j & 7], false);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 8; p++) { ur[p] = (ur[p] + 16) >> 5; ui[p] = (ui[p] + 16) >> 5; }
-
-        int ar[8], ai[8], br[8], bi[8];
-        ar[0] = ur[0] + ur[4]; ai[0] = ui[0] + ui[4];  ar[1] = ur[0] - ur[4]; ai[1] = ui[0] - ui[4];
-        ar[2] = ur[2] + ur[6]; ai[2] = ui[2] + ui[6];  ar[3] = ur[2] - ur[6]; ai[3] = ui[2] - ui[6];
-        ar[4] = ur[1] + ur[5]; ai[4] = ui[1] + ui[5];  ar[5] = ur[1] - ur[5]; ai[5] = ui[1] - ui[5];
-        ar[6] = ur[3] + ur[7]; ai[6] = ui[3] + ui[7];  ar[7] = ur[3] - ur[7]; ai[7] = ui[3] - ui[7];
-        br[0] = ar[0] + ar[2]; bi[0] = ai[0] + ai[2];  br[2] = ar[0] - ar[2]; bi[2] = ai[0] - ai[2];
-        br[1] = ar[1] + ai[3]; bi[1] = ai[1] - ar[3];  br[3] = ar[1] - ai[3]; bi[3] = ai[1] + ar[3];
-        br[4] = ar[4] + ar[6]; bi[4] = ai[4] + ai[6];  br[6] = ar[4] - ar[6]; bi[6] = ai[4] - ai[6];
-        br[5] = ar[5] + ai[7]; bi[5] = ai[5] - ar[7];  br[7] = ar[5] - ai[7]; bi[7] = ai[5] + ar[7];
-        const int w1r = mulc45(br[5] + bi[5]), w1i = mulc45(bi[5] - br[5]);
-        const int w3r = mulc45(bi[7] - br[7]), w3i = mulc45(-br[7] - bi[7]);
+        int yr[8], yi[8];
+        nvx_pfb_instant(&win[8 * lane], yr, yi);
         unsigned y[8];
-        y[0] = pack_clamp16(br[0] + br[4], bi[0] + bi[4]);  y[4] = pack_clamp16(br[0] - br[4], bi[0] - bi[4]);
-        y[1] = pack_clamp16(br[1] + w1r, bi[1] + w1i);      y[5] = pack_clamp16(br[1] - w1r, bi[1] - w1i);
-        y[2] = pack_clamp16(br[2] + bi[6], bi[2] - br[6]);  y[6] = pack_clamp16(br[2] - bi[6], bi[2] + br[6]);
-        y[3] = pack_clamp16(br[3] + w3r, bi[3] + w3i);      y[7] = pack_clamp16(br[3] - w3r, bi[3] - w3i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = ((unsigned)yr[k] & 0xffffu) | ((unsigned)yi[k] << 16);
 
         unsigned *out = a.sub + (size_t)wide * 8 * a.pitch_sub + a.sub_first + c * 64 + lane;
 #pragma unroll

@@ -127,6 +127,8 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
                       bool input_on_stream3 = false);
 // nvx_push_iq that reports how many samples it staged before NVX_ERR_FULL (or another error) stopped it
 int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted);
+// wideband handles: the fused kernel (default) or channeliser + cascade (NVX_WB_FUSED=0)
+bool nvx_wb_fused();
 // wait for every launched block, append bits, run the character layer (handle locked)
 int nvx_collect_locked(nvx_handle *h);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries

@@ -104,9 +104,25 @@ typedef struct {
     int chunks_per_block;
 } nvx_channelise_args;
 
+/* fused wideband kernel (nvx_wideband_fused.hip): n_wide streams at 2.016 MS/s -> 8 * n_wide decoded 252 kS/s streams */
+#define NVX_WB_SUBBANDS_K 8
+typedef struct {
+    const uint32_t *raw;       /* [n_wide][pitch] packed IQ at 2.016 MS/s                                    */
+    size_t pitch, first_sample;
+    int n_wide, n_frames;
+    const uint8_t *chain_masks;/* [8 * n_wide]                                                               */
+    const uint8_t *state_in;   /* cascade state blocks of the 8 * n_wide decoded streams, as nvx_cascade_args */
+    uint8_t *state_out;
+    const uint32_t *hist_in;   /* [n_wide][40] raw words in front of first_sample (NULL = silence)           */
+    uint32_t *hist_out;        /* [n_wide][40]: hand-over inside this launch and to the next one             */
+    double2 *y3; size_t y3_cap, y3_base;
+    int *queue, *status, *done;/* as nvx_cascade_args; done[n_wide]                                          */
+} nvx_wideband_args;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipStream_t s);
 hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStream_t s);
 hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s);
 hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s);

@@ -14,14 +14,16 @@ static int submit_locked(nvx_handle *h)
     const size_t dpitch = (size_t)h->cfg.max_frames * h->frame_in;
     // the other staging set must have left the copy engine before it is refilled
     if (h->stage_busy[nxt]) { HIP_TRY(hipEventSynchronize(h->stage_free[nxt])); h->stage_busy[nxt] = false; }
-    // d_in is reused by every launch: stream order makes its previous reader finish first (the cascade on
-    // h->stream, or in wideband mode the channeliser on stream3, which is why the copy goes there)
-    hipStream_t cs = h->cfg.wideband ? h->stream3 : h->stream;
+    // d_in is reused by every launch: stream order makes its previous reader finish first (the cascade or the fused
+    // wideband kernel on h->stream; in the two-kernel wideband form the channeliser on stream3, which is why the copy
+    // goes there then)
+    const bool on_stream3 = h->cfg.wideband && !nvx_wb_fused();
+    hipStream_t cs = on_stream3 ? h->stream3 : h->stream;
     HIP_TRY(hipMemcpy2DAsync(h->d_in, dpitch * 4, h->h_stage[cur], h->stage_cap * 4, take * 4, (size_t)h->n_in,
                              hipMemcpyHostToDevice, cs));
     HIP_TRY(hipEventRecord(h->stage_free[cur], cs));
     h->stage_busy[cur] = true;
-    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, h->cfg.wideband != 0);
+    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, on_stream3);
     if (rc != NVX_OK) return rc;
     // carry what was not submitted over to the other set
     for (int s = 0; s < h->n_in; s++) {

@@ -1,0 +1,167 @@
+// nvx_wideband_fused.hip -- the wideband receive path as ONE kernel (gfx950): a 2.016 MS/s stream is read from HBM once,
+// channelised into eight 252 kS/s sub-bands IN LDS, and every sub-band runs the two-chain cascade (FIR1 -> mixers ->
+// FIR2 -> FIR3) from there: 16 NAVTEX carriers per input stream, no sub-band round trip through HBM.
+// (nvx_channelise.hip + nvx_fir_cascade<false, 2> do the same through a [8 x n_wide][samples] buffer: 3 x the bytes.
+// That path stays behind NVX_WB_FUSED=0 for A/B runs and as the stand-alone channeliser of header section G.)
+//
+// No reference counterpart: the reference tunes ONE 252 kS/s slice (receiver/capt_sched.c:356-417); the cascade part is
+// the reference's arithmetic (nvx_cascade_wave.h), the channeliser is build-owned integer arithmetic (nvx_pfb.h).
+//
+// Mapping.  A work unit = one frame (315 passes) of one wideband stream, pulled from the same kind of atomic queue as
+// the cascade kernel's; a workgroup = 8 waves, wave k owns sub-band k (its polyphase window, mixer / FIR2 buffers and
+// histories: one CascadeLds<2> each, 8 x 17.4 KB) and the workgroup shares one raw window (40 halo + 2048 samples).
+// A pass = 256 channeliser output instants = 2048 raw samples = 8 KiB:
+//   1. every wave stores its prefetched 1-KiB piece into the raw window and requests the next pass's piece   | barrier
+//   2. every wave channelises 32 instants (a lane pair per instant, one component each) and writes the eight
+//      sub-band samples of every instant, as fp64, into the eight windows                                     | barrier
+//   3. every wave runs one cascade pass on its own window (CascadeWave<2>::compute_pass)
+// Two workgroup barriers per pass.  Filter histories and the 40-sample halo travel from unit (w, f) to (w, f+1)
+// through HBM exactly as in the cascade kernel: sc1 accesses, every storing wave drains (vmcnt 0), workgroup
+// barrier, one lane sets done[w]; the consumer's lane 0 polls, workgroup barrier, sc1 loads (MI355X_MICROARCH.md,
+// "Valid forms", first row).  Launches of few streams run their units one after the other (there is no pre-roll form
+// here); the grid is one workgroup per CU (LDS: 151 KB).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <mutex>
+
+#include "nvx_cascade_wave.h"
+#include "nvx_pfb.h"
+
+#define WB_SPIN_LIMIT (1 << 22)
+#define WB_PASS_WORDS 2048
+
+struct WidebandLds {
+    CascadeLds<2> sub[NVX_WB_SUBBANDS_K];
+    __attribute__((aligned(16))) unsigned raw[40 + WB_PASS_WORDS];
+    int unit, ok;
+};
+
+__global__ __launch_bounds__(512) void nvx_wideband_fused(nvx_wideband_args a)
+{
+    __shared__ WidebandLds L;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    CascadeWave<2> cw;
+    cw.init(&L.sub[wave], lane);
+    const int n_units = a.n_wide * a.n_frames;
+    // channeliser: lane = (instant, component); instant m = 32 * wave + (lane >> 1) of the pass -> phase m & 7,
+    // entry XH + (m >> 3) of every sub-band's window, component lane & 1
+    const int xslot = ((lane >> 1) & 7) * XS + XH + 4 * wave + (lane >> 4);
+
+    for (;;) {
+        // One lane dequeues for the workgroup.  The value goes through readfirstlane and is stored by the WHOLE of wave 0:
+        // with a lane-divergent store in front of the barrier the compiler threads the lanes that skip it straight to the
+        // barrier of the next iteration, wave 0's lane 0 then never gets to dequeue again (seen: every unit but the first
+        // re-ran unit 0 forever).
+        int next = 0;
+        if (tid == 0) next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        next = __builtin_amdgcn_readfirstlane(next);
+        if (wave == 0) L.unit = next;
+        __syncthreads();
+        const int u = L.unit;
+        if (u >= n_units) break;
+        const int part = u / a.n_wide;                  // frame of the launch
+        const int w = u - part * a.n_wide;              // wideband stream
+        const int s = NVX_WB_SUBBANDS_K * w + wave;     // decoded 252 kS/s stream of this wave
+        const unsigned mask = a.chain_masks[s];
+
+        // the input does not depend on the predecessor: request this wave's piece of the first pass now
+        const u32x4 *src = (const u32x4 *)(a.raw + ((size_t)w * a.pitch + a.first_sample) + (size_t)part * NVX_PASSES_PER_FRAME * WB_PASS_WORDS)
+                           + wave * 64 + lane;
+        u32x4 pf = __builtin_nontemporal_load(src);
+
+        // ------------------------------------------------------ wait for (w, part-1)
+        if (part > 0) {
+            if (wave == 0) {                            // wave-uniform; lane 0 polls, the whole wave agrees on the answer
+                int spins = 0, ok = 0;
+                do {
+                    int d = 0;
+                    if (lane == 0) d = __hip_atomic_load(a.done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    d = __builtin_amdgcn_readfirstlane(d);
+                    ok = d >= part;
+                    if (!ok) __builtin_amdgcn_s_sleep(32);
+                } while (!ok && ++spins < WB_SPIN_LIMIT);
+                if (spins > 0 && lane == 0) {
+                    __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!ok && lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up loudly rather than hang
+                L.ok = ok;
+            }
+            __syncthreads();                            // the other waves load the state only behind the poll
+            if (!L.ok) break;
+        }
+
+        // ------------------------------------------------------ state in (sc1 loads)
+        double2 *st = (double2 *)(a.state_out + (size_t)s * NVX_CASCADE_STATE_BYTES);
+        const double2 *st_in = (part == 0) ? (const double2 *)(a.state_in + (size_t)s * NVX_CASCADE_STATE_BYTES) : st;
+        cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_Y3_PER_FRAME, a.y3_cap, 0, 0, 0, true);
+        cw.state_in(st_in);
+        if (wave == 0 && lane < 40) {
+            const uint32_t *hin = (part == 0) ? a.hist_in : a.hist_out;
+            L.raw[lane] = hin ? __hip_atomic_load(hin + (size_t)w * 40 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+
+        for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass++) {
+            // ---- 1. this wave's 1 KiB of the pass into the raw window; next pass's piece requested
+            *(u32x4 *)&L.raw[40 + 256 * wave + 4 * lane] = pf;
+            src += WB_PASS_WORDS / 4;
+            if (pass + 1 < NVX_PASSES_PER_FRAME) pf = __builtin_nontemporal_load(src);
+            __syncthreads();                            // raw window complete; every wave is done with the last pass's windows
+            // ---- 2. channeliser: every wave 32 instants, a lane pair per instant (one component each); instant m's
+            //         48-word window is raw[8m .. 8m+47]
+            {
+                int y[8];
+                nvx_pfb_instant_split(&L.raw[8 * (32 * wave + (lane >> 1))], lane & 1, y);
+#pragma unroll
+                for (int k = 0; k < NVX_WB_SUBBANDS_K; k++)
+                    ((double *)&L.sub[k].X[xslot])[lane & 1] = (double)y[k];            // capt_sched.c:511: (double) of each short
+            }
+            __syncthreads();                            // windows filled; raw window consumed
+            // ---- 3. the newest 40 raw samples are the halo of the next pass (wave 7 owns that end of the window: its
+            //         own next store in step 1 follows this copy in its LDS queue); then the cascade pass
+            if (wave == 7 && lane < 40) { const unsigned t = L.raw[WB_PASS_WORDS + lane]; NVX_WAVE_LDS_FENCE(); L.raw[lane] = t; }
+            cw.compute_pass();
+        }
+
+        // ------------------------------------------------------ state out (sc1 stores), publish
+        NVX_WAVE_LDS_FENCE();
+        cw.state_out(st);
+        if (wave == 7 && lane < 40 && a.hist_out)
+            __hip_atomic_store(a.hist_out + (size_t)w * 40 + lane, L.raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains ...
+        __syncthreads();                                            // ... before the one lane that signals for all of them
+        // (the whole of wave 0 stores the same word: a lane-divergent store here is merged with the dequeue at the top of
+        // the loop into one "lane 0" region around the back-edge -- the deadlock described there)
+        if (wave == 0) __hip_atomic_store(a.done + w, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipStream_t s)
+{
+    // persistent grid: as many 8-wave workgroups as the device of this launch holds at once (LDS: one per CU)
+    static std::mutex mu;
+    static int resident_of[64];
+    int resident = 0;
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && resident_of[dev] > 0) resident = resident_of[dev];
+        else {
+            int cus = 0, per_cu = 0;
+            e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nvx_wideband_fused, 512, 0);
+            if (e != hipSuccess) return e;
+            resident = cus * (per_cu > 0 ? per_cu : 1);
+            if (dev >= 0 && dev < 64) resident_of[dev] = resident;
+        }
+    }
+    hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_wide) * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const long long units = (long long)a->n_wide * a->n_frames;
+    const unsigned grid = (unsigned)(units < resident ? units : resident);
+    hipLaunchKernelGGL(nvx_wideband_fused, dim3(grid), dim3(512), 0, s, *a);
+    return hipGetLastError();
+}

@@ -2,6 +2,9 @@
 channeliser.  CPU: the scalar restatement against an ideal float filter bank.
 GPU: the HIP kernel bit-exact against the restatement, and a wideband stream with
 16 NAVTEX carriers decoded end to end."""
+import json
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -156,3 +159,70 @@ def test_sixteen_carriers_from_one_wideband_stream(nv, oracle):
         p.flush()
         assert [p.bits(k, c) for k in range(8) for c in (0, 1)] == resident_bits
     d_raw.free(); d_sub.free()
+
+
+@pytest.mark.gpu
+def test_fused_wideband_kernel_against_the_restatement_chain_and_the_two_kernel_form(nv, oracle, tmp_path):
+    """The fused wideband kernel (default of a wideband handle) on several streams x several frames per launch, so that
+    units of one stream hand their histories over between workgroups: the 900 S/s output of all 16 chains of every
+    stream is bit-identical to channeliser restatement -> oracle cascade, bits too; masks select chains; and the
+    two-kernel form (NVX_WB_FUSED=0, separate process) produces the same digest."""
+    import hashlib, os, subprocess, sys
+    script = tmp_path / "wb.py"
+    script.write_text('''
+import sys, hashlib, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv
+W, F = 5, 7
+n = F * nv.FRAME_RAW
+rng = np.random.default_rng(11)
+raw = np.empty((W, n, 2), dtype=np.int16)
+for w in range(W):
+    carriers = []
+    for k in range(8):
+        centre = k * 252000 if k < 4 else (k - 8) * 252000
+        for c, off in ((0, 14000), (1, -14000)):
+            carriers.append(dict(freq_hz=centre + off, bits=nv.sitor_encode(f"ZCZC AA{(w + k + c) % 100:02d}\\nW{w} K{k} C{c}\\nNNNN\\n", 6),
+                                 bit_offset=(911 * (16 * w + 2 * k + c + 1)) % 20160, phase0=(7654321 * (16 * w + 2 * k + c + 1)) % 2**32, amplitude=1500))
+    raw[w] = nv.synth_host(nv.make_stream(carriers, seed=40 + w, noise_amp=500), nv.RATE_RAW, n)
+masks = [(3, 1, 2, 3, 3, 2, 1, 3)[(i + i // 8) % 8] for i in range(8 * W)]
+buf = nv.DeviceBuffer(W * n * 4)
+buf.upload(raw)
+h = hashlib.sha256()
+out = {}
+with nv.Pipeline(n_streams=W, wideband=True, chain_masks=masks, max_frames=4, char_layer=False) as p:
+    for f0, k in ((0, 4), (4, 3)):
+        p.process_resident(buf, n, f0, k); p.fetch()
+        for s in range(8 * W):
+            for c in range(2):
+                if (masks[s] >> c) & 1:
+                    y = p.debug_y3(s, c); h.update(y.tobytes())
+                    out.setdefault(f"{s}.{c}", []).append(y.tobytes().hex() if s in (0, 13, 39) else "")
+    bits = {f"{s}.{c}": p.bits(s, c) for s in range(8 * W) for c in range(2)}
+    for k in sorted(bits): h.update(bits[k].encode())
+np.save(sys.argv[2], raw)
+print(json.dumps({"digest": h.hexdigest(), "bits": bits, "masks": masks, "y3": {k: v for k, v in out.items() if v[0]}}))
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    recs = {}
+    for mode in ("1", "0"):
+        r = subprocess.run([sys.executable, str(script), root, str(tmp_path / "raw.npy")], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, NVX_WB_FUSED=mode))
+        assert r.returncode == 0, r.stderr[-3000:]
+        recs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert recs["1"]["digest"] == recs["0"]["digest"], "fused and two-kernel wideband forms differ"
+    rec = recs["1"]
+    raw = np.load(tmp_path / "raw.npy")
+    W, masks = raw.shape[0], rec["masks"]
+    for w in range(W):
+        sub = oracle.channelise(raw[w])
+        for k in range(8):
+            s = 8 * w + k
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False, tap_y3=7 * nv.FRAME_Y3)
+            ref.push(sub[k])
+            for c in range(2):
+                want = ref.bits(c) if (masks[s] >> c) & 1 else ""
+                assert rec["bits"][f"{s}.{c}"] == want, f"wide {w} band {k} chain {c}"
+                if f"{s}.{c}" in rec["y3"]:
+                    got = np.frombuffer(bytes.fromhex("".join(rec["y3"][f"{s}.{c}"])), dtype=np.float64).reshape(-1, 2)
+                    assert np.array_equal(got.view(np.uint64), np.ascontiguousarray(ref.y3(c)).view(np.uint64)), f"y3 of stream {s} chain {c}"
