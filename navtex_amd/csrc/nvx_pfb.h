@@ -1,7 +1,6 @@
 // nvx_pfb.h -- arithmetic of the 8-channel polyphase channeliser for ONE output instant (device code), shared by the
 // stand-alone kernel (nvx_channelise.hip) and the fused wideband kernel (nvx_wideband_fused.hip).
-// Definition (integer only; the test suite holds an independent scalar restatement of exactly these steps,
-// oracle/nvx_oracle.c:nvxo_channelise):
+// Definition (integer only; the test suite holds an independent scalar restatement of exactly these steps):
 //   u[p]  = (sum_{j = p mod 8} h[47-j] * x[8m-40+j] + 16) >> 5
 //   Y[k]  = radix-2 DIT DFT_8(u), 45-degree twiddles = 23170 / 2^15 with floor shifts
 //   out_k = clamp16((Y[k] + 4096) >> 13)
