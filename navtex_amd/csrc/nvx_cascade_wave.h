@@ -27,8 +27,8 @@
 //    (5 history entries: a lane reaches back 33 samples; 32 new ones).  37 is odd and = 5 mod 8, which spreads
 //    both write patterns (stage 0: ds_write_b64, lane pairs walk the phases; 252 kS/s input: ds_write_b128,
 //    lane parity picks the phase quartet) over all banks.
-// U[c]:  mixer output buffer, 46 history + pending (batch + up to 63)
-// Y2[c]: FIR2 output buffer, 70 history + pending (batch + one FIR2 run - 1)
+// U[c]:  mixer output buffer, 46 history + pending (struct Geo: at most 256 / 160)
+// Y2[c]: FIR2 output buffer, 70 history + one FIR3 batch
 // MIX:   2 signs x 2 periods x 9 x (cos, -+sin): index mixbase + (o mod 9) + 1 <= 17 needs no wrap, and the lane's
 //        sign of the cross product (step 4) is part of its table address
 #define XPH 8
@@ -44,13 +44,18 @@
 // (lane = chain x output x component), so half the batch fills the wave and the pending
 // buffers -- and with them the LDS footprint -- halve: 17.4 KB instead of 24 KB, 9 instead of 6
 // waves per CU.  Either way a frame (20160 / 2880 outputs) is a whole number of runs.
+// Fill levels.  A pass adds 64 mixer outputs, a FIR2 run takes U_RUN of them as soon as that many are pending: the
+// pending count walks 64, 128, 192, 256 -> 32, 96, 160, 224 -> 0 (one chain; a pre-roll starts the walk at 96) or
+// 64, 128 -> 16, 80, 144 -> 32, ... 112 -> 0 (two chains), so at most U_PEND_MAX are pending before a run and at most
+// U_LEFT_MAX after it.  FIR2 outputs collect to exactly Y2_RUN before FIR3 takes them all.
 template <int NCH> struct Geo;
-template <> struct Geo<1> { static constexpr int U_RUN = 224, Y2_PER_RUN = 32, Y2_RUN = NVX_Y2_RUN, Y3_PER_RUN = NVX_Y2_RUN / 10; };
-template <> struct Geo<2> { static constexpr int U_RUN = 112, Y2_PER_RUN = 16, Y2_RUN = 80, Y3_PER_RUN = 8; };
+template <> struct Geo<1> { static constexpr int U_RUN = 224, Y2_PER_RUN = 32, Y2_RUN = NVX_Y2_RUN, Y3_PER_RUN = NVX_Y2_RUN / 10, U_PEND_MAX = 256, U_LEFT_MAX = 32; };
+template <> struct Geo<2> { static constexpr int U_RUN = 112, Y2_PER_RUN = 16, Y2_RUN = 80, Y3_PER_RUN = 8, U_PEND_MAX = 160, U_LEFT_MAX = 48; };
 template <int NCH> struct GeoSizes {
-    static constexpr int U_ENTRIES = ((46 + Geo<NCH>::U_RUN + 63) + 7) / 8 * 8;
-    static constexpr int Y2_ENTRIES = ((70 + Geo<NCH>::Y2_RUN + Geo<NCH>::Y2_PER_RUN - 1) + 7) / 8 * 8;
+    static constexpr int U_ENTRIES = ((46 + Geo<NCH>::U_PEND_MAX) + 7) / 8 * 8;
+    static constexpr int Y2_ENTRIES = ((70 + Geo<NCH>::Y2_RUN) + 7) / 8 * 8;
 };
+static_assert(Geo<1>::U_RUN % 32 == 0 && Geo<2>::U_RUN % 16 == 0 && 46 + Geo<1>::U_LEFT_MAX <= 128 && 46 + Geo<2>::U_LEFT_MAX <= 128, "slide covers two rows of 64");
 
 template <int NCH>
 struct CascadeLds {
@@ -285,13 +290,14 @@ struct CascadeWave {
         // two chains put chain 0 on lanes 0-31 and chain 1 on lanes 32-63 (16 outputs each)
         const int f2c = (NCH == 2) ? (lane >> 5) : 0;
         const int f2o = (NCH == 2) ? ((lane >> 1) & 15) : half;
+        constexpr int UT1 = 46 + Geo<NCH>::U_LEFT_MAX - 64;        // entries of the second row that can survive a run
         while (n_u >= U_RUN) {
             // the pending entries behind this run move to the front afterwards: read them now, write them after the FIR
             nvx_d2 ut0[NCH], ut1[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 ut0[c] = *(const lds_vd2 *)&lds->U[c][U_RUN + lane];
-                ut1[c] = *(const lds_vd2 *)&lds->U[c][U_RUN + 64 + ((lane < 45) ? lane : 44)];
+                ut1[c] = *(const lds_vd2 *)&lds->U[c][U_RUN + 64 + (lane < UT1 ? lane : UT1 - 1)];
             }
             {
                 const lds_vdouble *ub = (const lds_vdouble *)((const double *)&lds->U[f2c][7 * f2o] + comp);
@@ -306,7 +312,7 @@ struct CascadeWave {
                 if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds->Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
             }
             NVX_WAVE_LDS_FENCE();
-            // drop the consumed inputs: keep 46 history + pending (<= 109 entries)
+            // drop the consumed inputs: keep 46 history + pending (<= 46 + U_LEFT_MAX entries)
             const int keep = 46 + n_u - U_RUN;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -328,7 +334,7 @@ struct CascadeWave {
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     yt0[c] = *(const lds_vd2 *)&lds->Y2[c][Y2_RUN + lane];
-                    yt1[c] = *(const lds_vd2 *)&lds->Y2[c][Y2_RUN + 64 + ((lane < 37) ? lane : 36) * (NCH == 1) + ((lane < 21) ? lane : 20) * (NCH == 2)];
+                    yt1[c] = *(const lds_vd2 *)&lds->Y2[c][Y2_RUN + 64 + (lane < 6 ? lane : 5)];      // 70 - 64 entries survive
                 }
                 {
                     const int ch = (NCH == 1) ? chain_of_slot0 : f3c;
@@ -347,7 +353,7 @@ struct CascadeWave {
                     }
                 }
                 NVX_WAVE_LDS_FENCE();
-                const int keep3 = 70 + n_y2 - Y2_RUN;           // <= 101 (one chain) / 85 (two chains)
+                const int keep3 = 70 + n_y2 - Y2_RUN;           // = 70: FIR3 runs the moment its batch is complete
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     if (lane < keep3) *(lds_vd2 *)&lds->Y2[c][lane] = yt0[c];
