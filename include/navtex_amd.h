@@ -249,7 +249,9 @@ NVX_API void  nvx_stream_destroy(int device, void *hip_stream);
  *    A group owns one handle and one host thread per member; global stream id g lives on member m with
  *    first(m) <= g < first(m) + count(m), first(m) = m * (S / n) + min(m, S % n).  The two chains of a stream stay
  *    together (they share FIR1).  cfg is read as for nvx_create with n_streams = the TOTAL S; chain_masks / labels
- *    are indexed by global stream; cfg.device is ignored; on_message receives the GLOBAL stream id.  Messages are
+ *    are indexed by global stream; cfg.device is ignored; on_message receives the GLOBAL stream id (wideband mode:
+ *    members own INPUT streams, decoded streams keep their meaning 8 * w + k with w the global input stream; that
+ *    is the id in messages, nvx_group_poll_bits and nvx_group_bit_count).  Messages are
  *    delivered by the thread that calls nvx_group_fetch_bits / nvx_group_flush, member after member, stream after
  *    stream -- the same order one handle of S streams would use.  Two members may name the same device.
  * ========================================================================== */

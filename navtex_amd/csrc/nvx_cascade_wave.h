@@ -140,6 +140,7 @@ struct CascadeWave {
     unsigned mask;                       // chains of the stream that are decoded
     int chain_of_slot0;                  // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
     int n_u, n_y2, n3_done, mixbase;
+    nvx_d2 mix_next;                     // mixer table entry of the NEXT pass's first output (= this pass's second one)
     bool emit;                           // FIR3 outputs are written (false during a pre-roll)
     double2 *y3; size_t y3_row0, y3_cap;
 
@@ -173,6 +174,7 @@ struct CascadeWave {
         mixrow = (const lds_vd2 *)&lds->mix[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
         y3 = y3_; y3_row0 = row0; y3_cap = cap;
         mixbase = mixbase0; n_u = n_u0; n_y2 = n_y20; n3_done = 0; emit = emit0;
+        mix_next = mixrow[mixbase];      // (behind init()'s table writes in this wave's LDS queue)
     }
 
     // filter histories from the state block: 36 newest 252 kS/s samples (oldest first), then per chain 46 mixer outputs
@@ -231,7 +233,9 @@ struct CascadeWave {
         // In front of them go the two reads whose results are only needed after FIR1 -- the mixer's table entries and
         // the tail of the new samples that becomes the next pass's history -- so that neither costs a round trip
         // through the LDS with the wave idle.
-        const nvx_d2 c0 = mixrow[mixbase], c1 = mixrow[mixbase + 1];
+        // (the lane's two outputs use table entries m and m + 1, the next pass's m + 1 and m + 2: one new entry per pass)
+        const nvx_d2 c0 = mix_next, c1 = mixrow[mixbase + 1];
+        mix_next = c1;
         nvx_d2 tail = { 0.0, 0.0 };
         if (lane < XPH * XH) tail = *(const lds_vd2 *)&lds->X[(lane & 7) * XS + 32 + (lane >> 3)];
         double xs[NVX_T1 + 4];

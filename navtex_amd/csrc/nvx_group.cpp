@@ -33,7 +33,8 @@ struct Member {
 
 struct nvx_group {
     nvx_config cfg{};
-    int total = 0;
+    int total = 0;                                // input streams (wideband: 2.016 MS/s inputs)
+    int per_in = 1;                               // decoded streams per input stream: 8 in wideband mode (stream 8 * w + k)
     std::vector<Member *> members;
     std::mutex api_mu;                            // one API call at a time (the members' handles have their own locks)
 };
@@ -41,7 +42,7 @@ struct nvx_group {
 static void member_on_message(void *user, int stream, const char *bbbb, const char *message, int freq)
 {
     Member *m = (Member *)user;
-    m->parked.push_back(GroupMsg{ m->first + stream, bbbb, message, freq });
+    m->parked.push_back(GroupMsg{ m->g->per_in * m->first + stream, bbbb, message, freq });
 }
 
 static void member_loop(Member *m)
@@ -134,7 +135,7 @@ extern "C" int nvx_group_create(const int *devices, int n_members, const nvx_con
     nvx_group *g = new nvx_group();
     g->cfg = *cfg; g->total = cfg->n_streams;
     // streams addressed by the caller: wideband inputs or plain streams; masks / labels are per DECODED stream
-    const int per_in = cfg->wideband ? NVX_WB_SUBBANDS : 1;
+    const int per_in = g->per_in = cfg->wideband ? NVX_WB_SUBBANDS : 1;
     const int base = g->total / n_members, extra = g->total % n_members;
     int hw = (int)std::thread::hardware_concurrency(); if (hw < 1) hw = 1;
     int first = 0;
@@ -229,20 +230,23 @@ extern "C" int nvx_group_flush(nvx_group *g)
     return group_join(g);
 }
 
+// decoded streams: in wideband mode global decoded stream 8 * w + k belongs to input stream w
 extern "C" size_t nvx_group_poll_bits(nvx_group *g, int s, int chain, char *out, size_t cap)
 {
-    const int mi = nvx_group_member_of(g, s);
+    if (!g || s < 0) return 0;
+    const int mi = nvx_group_member_of(g, s / g->per_in);
     if (mi < 0) return 0;
     Member *m = g->members[mi];
-    return nvx_poll_bits(m->h, s - m->first, chain, out, cap);
+    return nvx_poll_bits(m->h, s - g->per_in * m->first, chain, out, cap);
 }
 
 extern "C" size_t nvx_group_bit_count(nvx_group *g, int s, int chain)
 {
-    const int mi = nvx_group_member_of(g, s);
+    if (!g || s < 0) return 0;
+    const int mi = nvx_group_member_of(g, s / g->per_in);
     if (mi < 0) return 0;
     Member *m = g->members[mi];
-    return nvx_bit_count(m->h, s - m->first, chain);
+    return nvx_bit_count(m->h, s - g->per_in * m->first, chain);
 }
 
 // ------------------------------------------------------------------ NUMA placement

@@ -226,3 +226,96 @@ print(json.dumps({"digest": h.hexdigest(), "bits": bits, "masks": masks, "y3": {
                 if f"{s}.{c}" in rec["y3"]:
                     got = np.frombuffer(bytes.fromhex("".join(rec["y3"][f"{s}.{c}"])), dtype=np.float64).reshape(-1, 2)
                     assert np.array_equal(got.view(np.uint64), np.ascontiguousarray(ref.y3(c)).view(np.uint64)), f"y3 of stream {s} chain {c}"
+
+
+@pytest.mark.gpu
+def test_fused_kernel_unit_hand_over_chain(nv, oracle):
+    """Two wideband streams x 20 frames in ONE launch: every (stream, frame) unit gets its own workgroup and each stream is
+    a 20-deep chain of hand-overs (filter histories of 8 sub-bands x 2 chains and the channeliser's 40-sample halo) between
+    workgroups that all spin at once.  The complete 900 S/s output of every chain must be bit-exact against the
+    restatement chain; three rounds (L1-warm consumers on the later ones), then split into launches of 7 + 13 frames."""
+    W, F = 2, 20
+    n = F * nv.FRAME_RAW
+    rng = np.random.default_rng(21)
+    raw = rng.integers(-9000, 9000, size=(W, n, 2), dtype=np.int16)           # wideband noise: every sub-band busy
+    for w in range(W):
+        car = [dict(freq_hz=(k * 252000 if k < 4 else (k - 8) * 252000) + off, bits=nv.sitor_encode(f"ZCZC HO{k}{c}\nX\nNNNN\n", 8),
+                    bit_offset=1000 * k + 77 * c + 13 * w + 1, phase0=k * 999 + c, amplitude=1200) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
+        raw[w] = np.clip(raw[w].astype(np.int32) + nv.synth_host(nv.make_stream(car, seed=5 + w, noise_amp=0), nv.RATE_RAW, n), -32768, 32767).astype(np.int16)
+    want = {}
+    for w in range(W):
+        sub = oracle.channelise(raw[w])
+        for k in range(8):
+            ref = oracle.Pipe(chain_mask=3, charlayer=False, tap_y3=F * nv.FRAME_Y3)
+            ref.push(sub[k])
+            for c in range(2):
+                want[(8 * w + k, c)] = (np.ascontiguousarray(ref.y3(c)).view(np.uint64).copy(), ref.bits(c))
+    buf = nv.DeviceBuffer(W * n * 4)
+    buf.upload(raw)
+    with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=False) as p:
+        for rep, plan in enumerate(([F], [F], [F], [7, 13])):
+            p.reset()
+            got = {key: [] for key in want}
+            f0 = 0
+            for k in plan:
+                p.process_resident(buf, n, f0, k); f0 += k
+                p.fetch()
+                for (s, c) in want:
+                    got[(s, c)].append(p.debug_y3(s, c)[: k * nv.FRAME_Y3].copy())
+            for (s, c), (y3, bits) in want.items():
+                assert np.array_equal(np.concatenate(got[(s, c)]).view(np.uint64), y3), f"round {rep}: stream {s} chain {c}"
+                assert p.bits(s, c) == bits
+    buf.free()
+
+
+@pytest.mark.gpu
+def test_group_of_wideband_handles(nv, oracle):
+    """Wideband inputs sharded over group members: 3 wideband streams over 2 members (2 + 1), masks and labels per decoded
+    stream (8 per input), global ids in the messages."""
+    W, F = 3, 30
+    n = F * nv.FRAME_RAW
+    raw = np.empty((W, n, 2), dtype=np.int16)
+    texts = {}
+    for w in range(W):
+        car = []
+        for k in range(8):
+            centre = k * 252000 if k < 4 else (k - 8) * 252000
+            txt = f"ZCZC G{chr(65 + w)}{k:02d}\nW{w} B{k}\nNNNN\n"
+            texts[8 * w + k] = txt
+            car.append(dict(freq_hz=centre + 14000, bits=nv.sitor_encode(txt, 14), bit_offset=(1234 * (8 * w + k + 1)) % 20160, phase0=w * 77 + k, amplitude=2500))
+        raw[w] = nv.synth_host(nv.make_stream(car, seed=70 + w, noise_amp=800), nv.RATE_RAW, n)
+    masks = [1] * (8 * W)
+    labels = [[5000 + i, 0] for i in range(8 * W)]
+    bufs = [nv.DeviceBuffer(2 * n * 4), nv.DeviceBuffer(1 * n * 4)]
+    bufs[0].upload(raw[:2]); bufs[1].upload(raw[2:])
+    import ctypes as C
+    from navtex_amd import _native as N          # through the C ABI directly: the Python Group wrapper has no wideband switch
+    cfg = N.Config(); nv.lib.nvx_config_default(C.byref(cfg))
+    cfg.n_streams, cfg.wideband, cfg.max_frames, cfg.char_layer = W, 1, 10, 1
+    m_arr = (C.c_uint8 * len(masks))(*masks); cfg.chain_masks = m_arr
+    l_arr = (C.c_int * (2 * len(labels)))(*[v for pair in labels for v in pair]); cfg.labels = l_arr
+    msgs = []
+    cb = N.MESSAGE_FN(lambda u, s, b, m, f: msgs.append((s, f, b.decode(), m.decode()))); cfg.on_message = cb
+    devs = (C.c_int * 2)(0, 0)
+    g = C.c_void_p()
+    N.check(nv.lib.nvx_group_create(devs, 2, C.byref(cfg), C.byref(g)), "nvx_group_create")
+    try:
+        ptrs = (C.c_void_p * 2)(bufs[0].ptr, bufs[1].ptr)
+        for f0 in (0, 10, 20):
+            N.check(nv.lib.nvx_group_process_resident(g, ptrs, n, f0, 10), "process")
+        N.check(nv.lib.nvx_group_fetch_bits(g), "fetch")
+        # members own INPUT streams (2 + 1); decoded stream ids stay 8 * w + k with w the GLOBAL input stream
+        assert nv.lib.nvx_group_member_of(g, 0) == 0 and nv.lib.nvx_group_member_of(g, 1) == 0 and nv.lib.nvx_group_member_of(g, 2) == 1
+        assert msgs == sorted(msgs, key=lambda t: t[0])               # delivered member after member, stream after stream
+        assert [(s, f, b, m) for (s, f, b, m) in msgs] == [(i, 5000 + i, f"G{chr(65 + i // 8)}{i % 8:02d}", texts[i]) for i in range(8 * W)]
+        out = C.create_string_buffer(1 << 16)
+        for w in range(W):
+            sub = oracle.channelise(raw[w])
+            for k in (0, 5):
+                ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(sub[k])
+                nb = nv.lib.nvx_group_poll_bits(g, 8 * w + k, 0, out, 1 << 16)
+                assert out.raw[:nb].decode() == ref.bits(0) and nv.lib.nvx_group_bit_count(g, 8 * w + k, 0) == nb
+    finally:
+        nv.lib.nvx_group_destroy(g)
+    for b in bufs:
+        b.free()
