@@ -302,14 +302,20 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // LDS and does run beside the next cascade (NVX_FSM_OVERLAP=1, second stream), but what it hides (0.34 ms)
     // the cascade loses again (20.1 vs 19.8 ms): step time equal, so the default is one stream.
     static const bool fsm_overlap = getenv("NVX_FSM_OVERLAP") && atoi(getenv("NVX_FSM_OVERLAP")) == 1;
-    hipStream_t s2 = fsm_overlap ? h->stream2 : st;
+    // The whole demodulator of launch k runs on the second stream, beside the cascade of launch k + 1, whose persistent
+    // grid is one wave per CU short of what fits so that a workgroup of the front (14 KB of LDS) finds room on every CU:
+    // step 20.9 -> 20.5 ms on the headline workload (DESIGN.md tuning log).  NVX_DEMOD_OVERLAP=0 puts it back on the
+    // cascade's stream, =n (n > 1) caps the grid at n waves per CU instead (A/B runs).
+    static const int demod_overlap = getenv("NVX_DEMOD_OVERLAP") ? atoi(getenv("NVX_DEMOD_OVERLAP")) : 1;
+    hipStream_t s2 = (fsm_overlap || demod_overlap > 0) ? h->stream2 : st;
+    hipStream_t sd = demod_overlap > 0 ? h->stream2 : st;
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
     ca.state_in = h->d_cstate[h->launched & 1]; ca.state_out = h->d_cstate[(h->launched + 1) & 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
-    ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : 0;
+    ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : (demod_overlap > 1 ? demod_overlap : (demod_overlap == 1 ? -1 : 0));
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
@@ -338,14 +344,15 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     HIP_TRY(hipMemcpyAsync(h->h_status + 3 * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
     // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
-    if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], st));
-    HIP_TRY(nvx_launch_demod_front(&da, st));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], st));
-    HIP_TRY(hipEventRecord(h->demod_done[yb], st));      // y3[yb] consumed
+    if (sd != st) HIP_TRY(hipStreamWaitEvent(sd, h->casc_done[yb], 0));
+    else if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], sd));
+    HIP_TRY(nvx_launch_demod_front(&da, sd));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], sd));
+    HIP_TRY(hipEventRecord(h->demod_done[yb], sd));      // y3[yb] consumed
     h->demod_pending[yb] = true;
     // FSM + bit download behind the front
-    if (s2 != st) HIP_TRY(hipStreamWaitEvent(s2, h->demod_done[yb], 0));
+    if (s2 != sd) HIP_TRY(hipStreamWaitEvent(s2, h->demod_done[yb], 0));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[4], s2));
     HIP_TRY(nvx_launch_demod_fsm(&da, s2));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[5], s2));

@@ -316,6 +316,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     }
     int per_cu = fit_per_cu;
     if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;
+    if (a->max_waves_per_cu < 0 && per_cu + a->max_waves_per_cu >= 4) per_cu += a->max_waves_per_cu;     // "so many fewer than fit"
     const int resident = n_cus * per_cu;
     const long long units = (long long)a->n_streams * a->n_frames * NVX_UNIT_SPLIT;
     const unsigned grid = (unsigned)(units < resident ? units : resident);

@@ -50,11 +50,16 @@ enum { DI_SYNCED = 0, DI_SYNC_OFF, DI_NEXT_SYNC_OFF, DI_PHASE, DI_PREV_OFFSET, D
 static_assert(DI_COUNT == NVX_DEMOD_INTS && DS_COUNT == NVX_DEMOD_DOUBLES && DI_PREV_OFFSET == NVX_DI_PREV_OFFSET &&
               DI_PHASE == NVX_DI_PHASE, "state layout");
 
+// Workgroup shape: 128 threads on a time tile of 432 samples (a multiple of 9: whole bit periods) = 15.4 KB of LDS, so that a workgroup
+// finds room on a CU beside the NEXT launch's persistent cascade grid (the host runs the demodulator of launch k
+// beside the cascade of launch k + 1).  Stand-alone the shapes 256 / 1152 and 192 / 576 were equally fast in round 1
+// (0.68 / 0.72 ms).
 #ifndef NVX_FRONT_THREADS
-#define NVX_FRONT_THREADS 256
+#define NVX_FRONT_THREADS 128
 #endif
 #ifndef DTL
-#define DTL 1152                         // time tile: 4 frames of 900 S/s samples (multiple of 9)
+#define DTL 432
+static_assert(DTL % 9 == 0, "a tile is a whole number of bit periods");
 #endif
 #define FRONT_SLIDE ((567 + NVX_FRONT_THREADS - 1) / NVX_FRONT_THREADS)
 #define G_DAB 8

@@ -56,7 +56,7 @@ typedef struct {
     int *status;               /* = queue + 1                                          */
     int *done;                 /* = queue + 2: frames completed per stream             */
     int independent;           /* set by the launcher: units do not wait for their predecessor (pre-roll instead) */
-    int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid      */
+    int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid; <0 = that many fewer than fit */
 } nvx_cascade_args;
 
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares
