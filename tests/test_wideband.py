@@ -319,3 +319,36 @@ def test_group_of_wideband_handles(nv, oracle):
         nv.lib.nvx_group_destroy(g)
     for b in bufs:
         b.free()
+
+
+@pytest.mark.gpu
+def test_wideband_full_size_total_parity(nv, oracle):
+    """The wideband bench workload at full size (512 streams x 2.016 MS/s x 12 frames = 15.9 GB, 8192 carriers): EVERY
+    carrier's bits from the fused kernel equal the restatement chain's (oracle channeliser -> 8 x two-chain oracle
+    pipelines, OpenMP over the wideband streams), and no bit-timing decision is near a tie."""
+    import os, sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench, signals
+    W, F = 512, 12
+    n = F * nv.FRAME_RAW
+    try:
+        buf = nv.DeviceBuffer(W * n * 4)
+    except nv.NvxError:
+        pytest.skip("not enough device memory")
+    nv.synth_device(bench.wideband_streams(nv, signals, 0, W), nv.RATE_RAW, n, buf, n)
+    ncpu = min(16, len(os.sched_getaffinity(0)))
+    with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=False) as p:
+        p.process_resident(buf, n, 0, F)
+        p.fetch()
+        bad, chunk = [], 32
+        for w0 in range(0, W, chunk):
+            sample = buf.download(chunk * n * 4, offset=w0 * n * 4, dtype=np.int16).reshape(chunk, n, 2)
+            _secs, want = oracle.bench_wide(sample, chunk, n // 8, ncpu, want_bits=True)
+            for i, bits in enumerate(want):
+                s, c = 8 * w0 + i // 2, i % 2
+                if p.bits(s, c) != bits or len(bits) < 300:
+                    bad.append((s, c))
+        near, evals, margin = p.tie_stats()
+    buf.free()
+    assert bad == [], f"{len(bad)} of {16 * W} carriers differ: {bad[:10]}"
+    assert near == 0 and evals > 16 * W * 250
