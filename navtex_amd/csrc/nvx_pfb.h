@@ -73,7 +73,8 @@ __device__ __forceinline__ void nvx_pfb_instant(const unsigned *win, int (&yr)[8
 __device__ __forceinline__ void nvx_pfb_instant_split(const unsigned *win, int c, int (&y)[8])
 {
     const int sh = 16 * c, sm = -c;                  // selector shift; sign mask: (v ^ sm) - sm = sigma * v
-    int u[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    // the rounding constant of the branch sums starts in the accumulators: (sum + 16) >> 5
+    int u[8] = { 16, 16, 16, 16, 16, 16, 16, 16 };
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         const u32x4 w = *(const u32x4 *)&win[4 * r];
@@ -86,9 +87,13 @@ __device__ __forceinline__ void nvx_pfb_instant_split(const unsigned *win, int c
         }
     }
 #pragma unroll
-    for (int p = 0; p < 8; p++) u[p] = (u[p] + 16) >> 5;
+    for (int p = 0; p < 8; p++) u[p] >>= 5;
+    // Branch 0 enters every output of the transform with weight +1 and none of the values fetched from the partner lane
+    // (a3, a7, b5, b6, b7 below) contains it, so the output rounding constant (Y + 4096) >> 13 is added once, here.
+    u[0] += 4096;
     auto swap = [](int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); };      // the partner lane's value
     auto sig = [sm](int v) { return (v ^ sm) - sm; };
+    auto out = [](int v) { v >>= 13; return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); };
     int a[8], b[8];
     a[0] = u[0] + u[4]; a[1] = u[0] - u[4]; a[2] = u[2] + u[6]; a[3] = u[2] - u[6];
     a[4] = u[1] + u[5]; a[5] = u[1] - u[5]; a[6] = u[3] + u[7]; a[7] = u[3] - u[7];
@@ -97,10 +102,10 @@ __device__ __forceinline__ void nvx_pfb_instant_split(const unsigned *win, int c
     b[1] = a[1] + o3;   b[3] = a[1] - o3;   b[5] = a[5] + o7;   b[7] = a[5] - o7;
     const int o5 = sig(swap(b[5])), o6 = sig(swap(b[6])), o7b = sig(swap(b[7]));
     const int w1 = mulc45(b[5] + o5), w3 = mulc45(o7b - b[7]);
-    y[0] = round_clamp16(b[0] + b[4]); y[4] = round_clamp16(b[0] - b[4]);
-    y[1] = round_clamp16(b[1] + w1);   y[5] = round_clamp16(b[1] - w1);
-    y[2] = round_clamp16(b[2] + o6);   y[6] = round_clamp16(b[2] - o6);
-    y[3] = round_clamp16(b[3] + w3);   y[7] = round_clamp16(b[3] - w3);
+    y[0] = out(b[0] + b[4]); y[4] = out(b[0] - b[4]);
+    y[1] = out(b[1] + w1);   y[5] = out(b[1] - w1);
+    y[2] = out(b[2] + o6);   y[6] = out(b[2] - o6);
+    y[3] = out(b[3] + w3);   y[7] = out(b[3] - w3);
 }
 
 #endif

@@ -234,11 +234,20 @@ def test_fused_kernel_unit_hand_over_chain(nv, oracle):
     a 20-deep chain of hand-overs (filter histories of 8 sub-bands x 2 chains and the channeliser's 40-sample halo) between
     workgroups that all spin at once.  The complete 900 S/s output of every chain must be bit-exact against the
     restatement chain; three rounds (L1-warm consumers on the later ones), then split into launches of 7 + 13 frames."""
-    W, F = 2, 20
+    W, F = 3, 20
     n = F * nv.FRAME_RAW
     rng = np.random.default_rng(21)
     raw = rng.integers(-9000, 9000, size=(W, n, 2), dtype=np.int16)           # wideband noise: every sub-band busy
-    for w in range(W):
+    # third stream: full-scale random with saturating stretches (constant +-full scale, full-scale tones at sub-band
+    # centres): the output clamp of the channeliser and the largest intermediate values of its transform
+    raw[2] = rng.integers(-32768, 32768, size=(n, 2), dtype=np.int16)
+    raw[2, 5000:60000] = 32767; raw[2, 90000:140000] = -32768
+    t = np.arange(200000)
+    for k, at in ((1, 300000), (3, 600000), (6, 900000)):
+        ph = 2 * np.pi * k * t / 8.0 + 0.3
+        raw[2, at:at + t.size, 0] = np.clip(np.round(32767.0 * np.cos(ph)), -32768, 32767).astype(np.int16)
+        raw[2, at:at + t.size, 1] = np.clip(np.round(32767.0 * np.sin(ph)), -32768, 32767).astype(np.int16)
+    for w in range(2):
         car = [dict(freq_hz=(k * 252000 if k < 4 else (k - 8) * 252000) + off, bits=nv.sitor_encode(f"ZCZC HO{k}{c}\nX\nNNNN\n", 8),
                     bit_offset=1000 * k + 77 * c + 13 * w + 1, phase0=k * 999 + c, amplitude=1200) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
         raw[w] = np.clip(raw[w].astype(np.int32) + nv.synth_host(nv.make_stream(car, seed=5 + w, noise_amp=0), nv.RATE_RAW, n), -32768, 32767).astype(np.int16)
