@@ -258,7 +258,10 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (n_frames < 1 || n_frames > h->cfg.max_frames) { nvx_set_error("n_frames %d outside 1..max_frames %d", n_frames, h->cfg.max_frames); return NVX_ERR_ARG; }
     if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
     Result &r = h->res[h->launched % RESULT_SLOTS];
-    if (r.pending) { int rc = nvx_collect_locked(h); if (rc != NVX_OK) return rc; }
+    // Ring full: take in the OLDEST result only (launched RESULT_SLOTS launches ago, long finished), so that the launches
+    // behind it keep the GPU busy while the host appends its bits.  (Collecting everything here drained the pipeline every
+    // RESULT_SLOTS launches: a demodulator running alone plus the host's character layer, 0.5-1 ms per step.)
+    if (r.pending) { int rc = nvx_collect_locked(h, h->launched - RESULT_SLOTS + 1); if (rc != NVX_OK) return rc; }
 
     // a launch on another stream than its predecessor: order it behind the predecessor's last operation
     if (h->launch_done_valid && st != h->last_launch_stream) HIP_TRY(hipStreamWaitEvent(st, h->launch_done, 0));
@@ -371,10 +374,11 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     return NVX_OK;
 }
 
-// wait for every launched block, append bits, run the character layer
-int nvx_collect_locked(nvx_handle *h)
+// wait for the launched blocks in front of `upto` (default: all of them), append bits, run the character layer
+int nvx_collect_locked(nvx_handle *h, uint64_t upto)
 {
-    while (h->collected < h->launched) {
+    if (upto > h->launched) upto = h->launched;
+    while (h->collected < upto) {
         Result &r = h->res[h->collected % RESULT_SLOTS];
         if (r.pending) {
             HIP_TRY(hipEventSynchronize(r.done));

@@ -129,8 +129,9 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
 int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted);
 // wideband handles: the fused kernel (default) or channeliser + cascade (NVX_WB_FUSED=0)
 bool nvx_wb_fused();
-// wait for every launched block, append bits, run the character layer (handle locked)
-int nvx_collect_locked(nvx_handle *h);
+// wait for the launched blocks in front of launch number `upto` (default: every one), append bits, run the character
+// layer (handle locked)
+int nvx_collect_locked(nvx_handle *h, uint64_t upto = UINT64_MAX);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries
 const uint32_t *nvx_fsm_table_host();
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# demodulator timing of kernel builds: gpu_demod_ab.sh LIB...; prints demod_avg_launch_ms (front + FSM) per build
+# demodulator timing of kernel builds: gpu_demod_ab.sh LIB...; prints demod_span_ms (front + FSM) per build
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 mkdir -p $R/gpurun_out; L=$R/gpurun_out/demod_ab.log; : > $L
 for lib in "$@"; do
@@ -15,5 +15,5 @@ for line in open("$L"):
     if line.startswith("=="): tag=line[3:]
     elif line.startswith("{"):
         j=json.loads(line)
-        print(f"{tag:45s} step {j['ms_per_step']:.3f} ms  demod {j['roofline'].get('demod_avg_launch_ms')} ms  parity {j.get('parity')}")
+        print(f"{tag:45s} step {j['ms_per_step']:.3f} ms  demod {j['roofline'].get('demod_span_ms')} ms  parity {j.get('parity')}")
 PY
