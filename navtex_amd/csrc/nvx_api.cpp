@@ -262,6 +262,18 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // behind it keep the GPU busy while the host appends its bits.  (Collecting everything here drained the pipeline every
     // RESULT_SLOTS launches: a demodulator running alone plus the host's character layer, 0.5-1 ms per step.)
     if (r.pending) { int rc = nvx_collect_locked(h, h->launched - RESULT_SLOTS + 1); if (rc != NVX_OK) return rc; }
+    // ... and whatever else has finished meanwhile (no waiting): its bits and messages reach the user now, behind the
+    // launches that are still queued on the GPU, instead of with the next fetch
+    while (h->collected < h->launched) {
+        Result &o = h->res[h->collected % RESULT_SLOTS];
+        if (o.pending) {
+            const hipError_t q = hipEventQuery(o.done);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (q != hipSuccess) { nvx_set_error("hipEventQuery: %s", hipGetErrorString(q)); return NVX_ERR_HIP; }
+        }
+        int rc = nvx_collect_locked(h, h->collected + 1);
+        if (rc != NVX_OK) return rc;
+    }
 
     // a launch on another stream than its predecessor: order it behind the predecessor's last operation
     if (h->launch_done_valid && st != h->last_launch_stream) HIP_TRY(hipStreamWaitEvent(st, h->launch_done, 0));
