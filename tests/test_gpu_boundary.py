@@ -144,6 +144,36 @@ def test_launch_partitioning_is_invisible(nv):
     buf.free()
 
 
+def test_results_arrive_behind_the_launches_without_a_fetch(nv):
+    """A receiver that only ever calls process_resident (no fetch, no poll) still gets its messages: a launch takes in
+    every earlier result that has finished, and a full result ring takes in its oldest one only.  Same bits and messages
+    as one launch followed by a fetch."""
+    import time
+    import signals
+    n_streams, frames = 3, 75                                      # 24 s: the whole message of every stream
+    streams = [signals.stream_params(nv, 4200 + s, nv.RATE_RAW)[0] for s in range(n_streams)]
+    pitch = frames * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(n_streams * pitch * 4)
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    with nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=frames) as p:
+        p.process_resident(buf, pitch, 0, frames)
+        p.fetch()
+        want_bits = [p.bits(s, 0) for s in range(n_streams)]
+        want_msgs = sorted(p.messages)
+        assert len(want_msgs) == n_streams
+        p.reset(); p.messages.clear()
+        seen_before_fetch = 0
+        for f in range(frames):                                    # 75 launches through a ring of four results
+            p.process_resident(buf, pitch, f, 1)
+            if f >= frames - 3: time.sleep(0.05)                   # the earlier launches have certainly finished by now
+            seen_before_fetch = len(p.messages)
+        assert seen_before_fetch == n_streams, "messages must not wait for a fetch"
+        p.fetch()
+        assert [p.bits(s, 0) for s in range(n_streams)] == want_bits
+        assert sorted(p.messages) == want_msgs
+    buf.free()
+
+
 def test_callback_from_a_producer_thread_while_polling(nv, oracle):
     """SURVEY 8(f) rank 1 in miniature: a 'vendor' thread delivers jittered callbacks while
     the consumer thread polls bits -- the library's locking must keep the stream intact."""
