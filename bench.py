@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--wideband", type=int, default=0, metavar="W",
                     help="wideband mode (SURVEY 8f rank 2, not the headline): W streams at 2.016 MS/s per GPU, each carrying "
                          "16 NAVTEX carriers; channeliser -> 8W sub-bands at 252 kS/s -> both chains")
+    ap.add_argument("--stage0", choices=("boxcar", "cic3"), default="boxcar",
+                    help="raw-rate front end: integrate-and-dump (default, the headline) or its third-order form "
+                         "(nvx_config.stage0_order = 3: 76 dB of alias rejection instead of 25)")
     ap.add_argument("--variant-a", action="store_true",
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
@@ -138,7 +141,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def reference_check(ob, raw_stream):
+def reference_check(ob, raw_stream, order=1):
     """Strawman guard: the reference ITSELF (oracle/_ref/ref_bits, built from /root/reference in the
     build container and shipped as a binary) against the port, one thread each, on the same 252 kS/s input
     (the stream's stage-0 output; the reference always runs both chains).  None when the binary is absent."""
@@ -147,7 +150,7 @@ def reference_check(ob, raw_stream):
     if not exe.exists():
         return None
     try:
-        iq252 = ob.stage0(raw_stream)[: 252000 * 4]
+        iq252 = (ob.stage0_cic3 if order == 3 else ob.stage0)(raw_stream)[: 252000 * 4]
         with tempfile.TemporaryDirectory() as td:
             f = Path(td) / "in.bin"; iq252.tofile(f)
             t0 = time.perf_counter()
@@ -361,6 +364,8 @@ def main():
     import fullsize
     S, F = args.streams, args.frames
     raw = not args.variant_a
+    order = 3 if (raw and args.stage0 == "cic3") else 1
+    oraw = (3 if order == 3 else True) if raw else False          # what the oracle is told: its raw flag carries the order
     RATE, FRAME = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)
     n_per_stream = F * FRAME
     pitch = n_per_stream + args.pitch_pad
@@ -379,7 +384,7 @@ def main():
     t_gen = time.time() - t0
 
     pipe = nv.Pipeline(n_streams=S, raw_rate=raw, chain_mask=nv.CHAIN_518, max_frames=F,
-                       char_layer=not args.no_charlayer, device=device)
+                       char_layer=not args.no_charlayer, device=device, stage0_order=order)
     ncpu = place["threads"]
 
     # ---- parity gate: EVERY rank checks its own shard against the oracle, from reset state -----------------------
@@ -387,7 +392,7 @@ def main():
     pipe.fetch()
     n_verify = args.verify if args.verify > 0 else (S if world == 1 else 32)
     ids = fullsize.spread(S, n_verify)
-    checked, bad, verify_s = fullsize.verify_streams(ob, buf, pitch, n_per_stream, raw, lambda s: pipe.bits(s, 0), ids, ncpu)
+    checked, bad, verify_s = fullsize.verify_streams(ob, buf, pitch, n_per_stream, oraw, lambda s: pipe.bits(s, 0), ids, ncpu)
     if bad:
         print(f"PARITY FAILURE (rank {rank}): {len(bad)} of {checked} streams differ from the CPU oracle, first {bad[:8]}", file=sys.stderr)
     parity = ranks.reduce(0.0 if bad else 1.0, "min") > 0.5
@@ -406,11 +411,11 @@ def main():
         n252 = F * nv.FRAME_IN
         per_pass = n_cs * n_per_stream
         # calibrate, then size the repeat count for ~6 s wall on all threads
-        sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu)[0]
+        sN = ob.bench(sample, n_cs, n252, oraw, 1, ncpu)[0]
         rep = max(1, int(6.0 / max(sN, 1e-3)))
-        sN = ob.bench(sample, n_cs, n252, raw, 1, ncpu, repeat=rep)[0]
+        sN = ob.bench(sample, n_cs, n252, oraw, 1, ncpu, repeat=rep)[0]
         one = min(n_cs, 2)
-        s1 = ob.bench(sample[:one], one, n252, raw, 1, 1, repeat=max(1, rep // 8))[0]
+        s1 = ob.bench(sample[:one], one, n252, oraw, 1, 1, repeat=max(1, rep // 8))[0]
         cpu = {
             "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
             "cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
@@ -419,7 +424,7 @@ def main():
                       f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
             "seconds": round(sN, 2),
         }
-        cpu["reference_check"] = reference_check(ob, sample[0]) if raw else None
+        cpu["reference_check"] = reference_check(ob, sample[0], order) if raw else None
     pipe.reset()
 
     # ---- warm-up, then EXACTLY K timed steps ------------------------------------
@@ -457,12 +462,12 @@ def main():
         if tf.exists():
             try:
                 rec = json.loads(tf.read_text())
-                if rec.get("streams") == S and rec.get("frames") == F:
+                if rec.get("streams") == S and rec.get("frames") == F and order == 1:
                     traffic = rec.get("bytes_per_launch")
                     traffic_source = "profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured by this run)"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>", "achieved": round(achieved, 1) if achieved else None,
+        roofline = {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>" if order == 1 else "nvx_fir_cascade_cic3_1", "achieved": round(achieved, 1) if achieved else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_step,
                     "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
@@ -486,7 +491,9 @@ def main():
                                (f"VARIANT A (not the headline): {S} channels x 252 kS/s int16 IQ per GPU, {F} frames ({F * 0.32:.2f} s), "
                                 f"no stage 0 -- fp64-issue-bound by design (SURVEY 7-2)"),
                    "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step,
-                   "stage0": "integrate-and-dump /8 (build-owned)" if raw else "none", "chains_per_stream": 1,
+                   "stage0": ("none" if not raw else "integrate-and-dump /8 (build-owned)" if order == 1 else
+                              "three cascaded 8-sample boxcars /8 = 22-tap CIC^3 (build-owned; NOT the headline front end)"),
+                   "chains_per_stream": 1,
                    "parallelism": f"streams sharded {world} ways, no collective"},
         "roofline": roofline,
         "cpu_baseline": cpu,

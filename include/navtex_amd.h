@@ -155,6 +155,13 @@ typedef struct nvx_config {
     int      bit_history;     /* decoded bits kept per chain for nvx_poll_bits (0 = NVX_BIT_HISTORY) */
     int      host_threads;    /* threads the character layer of one collect may use (0 = NVX_HOST_THREADS or   */
                               /* the hardware's count, at most 16)                                             */
+    int      stage0_order;    /* raw_rate = 1 only.  0 / 1: stage 0 is an integrate-and-dump over 8 samples,          */
+                              /*   out = (sum + 4) >> 3 (25 dB of alias rejection at the NAVTEX offsets);             */
+                              /* 3: three such boxcars in cascade (a third-order CIC as its 22-tap FIR,               */
+                              /*   w = 1 3 6 10 15 21 28 36 42 46 48 48 46 ... 3 1):  out = (sum w x + 256) >> 9,     */
+                              /*   76 dB of alias rejection, 14 samples of carried history, ~7 % more kernel time.    */
+                              /* Both are build-owned integer definitions (the reference starts at 252 kS/s:          */
+                              /* receiver/capt_sched.c:31-34); anything else is NVX_ERR_ARG.                           */
 } nvx_config;
 
 /* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the

@@ -32,6 +32,7 @@ class Config(C.Structure):
         ("wideband", C.c_int),
         ("bit_history", C.c_int),
         ("host_threads", C.c_int),
+        ("stage0_order", C.c_int),
     ]
 
 

@@ -105,6 +105,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
 {
     if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1) { nvx_set_error("nvx_create: bad config"); return NVX_ERR_ARG; }
     *out = nullptr;
+    if (cfg->stage0_order != 0 && cfg->stage0_order != 1 && cfg->stage0_order != 3) { nvx_set_error("nvx_create: stage0_order %d (1 or 3)", cfg->stage0_order); return NVX_ERR_ARG; }
+    if (cfg->stage0_order == 3 && !(cfg->raw_rate && !cfg->wideband)) { nvx_set_error("nvx_create: stage0_order 3 needs raw_rate input (a wideband handle has its channeliser, 252 kS/s input no stage 0)"); return NVX_ERR_ARG; }
     int rc = nvx_select_device(cfg->device);
     if (rc != NVX_OK) return rc;
 
@@ -330,6 +332,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     ca.state_in = h->d_cstate[h->launched & 1]; ca.state_out = h->d_cstate[(h->launched + 1) & 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
+    ca.stage0_order = h->cfg.stage0_order;
     ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : (demod_overlap > 1 ? demod_overlap : (demod_overlap == 1 ? -1 : 0));
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;

@@ -115,6 +115,56 @@ __device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
 }
 #endif
 
+// Stage 0, third-order form (nvx_config.stage0_order = 3): three cascaded 8-sample boxcars decimated by 8, i.e. the
+// 22-tap filter w = 1 3 6 10 15 21 28 36 42 46 48 48 46 ... 3 1 (sum 512):  y[k] = (sum_j w[j] x[8k+7-j] + 256) >> 9.
+// 76 dB of alias rejection at the NAVTEX offsets where the integrate-and-dump has 25.
+// Per block b of 8 samples three weighted sums:  A_b = sum_i w[7-i] x_i,  B_b = sum_i w[15-i] x_i,  C_b = sum_i w[23-i] x_i
+// (w[22] = w[23] = 0), and y[k] = A_k + B_(k-1) + C_(k-2).  Lanes as in the first-order form: the pair (2i, 2i+1) holds
+// block i of the load, four samples each; a lane sums both components of its four samples (v_perm de-interleaves them
+// into (x_i, x_i+1) half-word pairs -- its own component and the partner's, the selector is per lane -- and
+// v_dot2_i32_i16 multiplies a pair by a weight pair), keeps its own component and hands the other to its partner
+// (DPP pair swap).  The two block delays are two rotations of the wave by one lane pair (wave_ror:1 twice); lanes 62 / 63
+// of the rotated value come from the previous load, so that its last block lands in front of this load's first:
+//      t_b = B_b + C_(b-1),  y_b = A_b + t_(b-1).
+// 27 VALU instructions per load (first-order form: 11).  Carried between units: lanes 62 / 63 of (C, t) of the last
+// load, four integers, entry NVX_CASCADE_STATE_ENTRIES - 1 of the state block.
+struct Stage0Cic3 {
+    unsigned sel_mine, sel_other;            // v_perm selectors: low halves (I) or high halves (Q) of two words
+    unsigned wa0, wa1, wb0, wb1, wc0, wc1;   // weight pairs of this lane's samples (0..3 on even lanes, 4..7 on odd ones)
+    int c_prev, t_prev;                      // C and t of the previous load
+    bool last_pair;                          // lanes 62, 63
+
+    __device__ __forceinline__ void init(int lane)
+    {
+        const bool odd = lane & 1;
+        sel_mine = odd ? 0x07060302u : 0x05040100u;
+        sel_other = odd ? 0x05040100u : 0x07060302u;
+        // w[7-i], w[15-i], w[23-i] for i = 0..3 (even lanes) or 4..7 (odd lanes), packed (first | second << 16)
+        wa0 = odd ? (10u | 6u << 16) : (36u | 28u << 16);  wa1 = odd ? (3u | 1u << 16) : (21u | 15u << 16);
+        wb0 = odd ? (48u | 48u << 16) : (28u | 36u << 16); wb1 = odd ? (46u | 42u << 16) : (42u | 46u << 16);
+        wc0 = odd ? (6u | 10u << 16) : 0u;                 wc1 = odd ? (15u | 21u << 16) : (1u | 3u << 16);
+        last_pair = lane >= 62;
+        c_prev = 0; t_prev = 0;
+    }
+    __device__ __forceinline__ static int rot1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }   // wave_ror:1: lane l reads lane l-1, lane 0 lane 63
+    __device__ __forceinline__ double step(u32x4 v)
+    {
+        const nvx_short2 m01 = as_short2(__builtin_amdgcn_perm(v.y, v.x, sel_mine)), m23 = as_short2(__builtin_amdgcn_perm(v.w, v.z, sel_mine));
+        const nvx_short2 o01 = as_short2(__builtin_amdgcn_perm(v.y, v.x, sel_other)), o23 = as_short2(__builtin_amdgcn_perm(v.w, v.z, sel_other));
+        int ma = __builtin_amdgcn_sdot2(m01, as_short2(wa0), 256, false); ma = __builtin_amdgcn_sdot2(m23, as_short2(wa1), ma, false);   // + 256: round half up
+        int mb = __builtin_amdgcn_sdot2(m01, as_short2(wb0), 0, false);   mb = __builtin_amdgcn_sdot2(m23, as_short2(wb1), mb, false);
+        int mc = __builtin_amdgcn_sdot2(m01, as_short2(wc0), 0, false);   mc = __builtin_amdgcn_sdot2(m23, as_short2(wc1), mc, false);
+        int oa = __builtin_amdgcn_sdot2(o01, as_short2(wa0), 0, false);   oa = __builtin_amdgcn_sdot2(o23, as_short2(wa1), oa, false);
+        int ob = __builtin_amdgcn_sdot2(o01, as_short2(wb0), 0, false);   ob = __builtin_amdgcn_sdot2(o23, as_short2(wb1), ob, false);
+        int oc = __builtin_amdgcn_sdot2(o01, as_short2(wc0), 0, false);   oc = __builtin_amdgcn_sdot2(o23, as_short2(wc1), oc, false);
+        const int A = ma + dpp_swap_pairs(oa), B = mb + dpp_swap_pairs(ob), C = mc + dpp_swap_pairs(oc);
+        const int t = B + rot1(rot1(last_pair ? c_prev : C));
+        const int y = A + rot1(rot1(last_pair ? t_prev : t));
+        c_prev = C; t_prev = t;
+        return (double)(y >> 9);             // arithmetic shift = floor
+    }
+};
+
 template <bool RAW, bool NT>
 __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 *src)
 {
@@ -143,8 +193,13 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // latency-bound tail of 1280; frame-sized units keep every CU full to the end.
 #define NVX_SPIN_LIMIT (1 << 22)
 
-template <bool RAW, int NCH, int PFD, bool NT>
-__global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
+// ARGS: how the wave sees the kernel's argument block.  By reference the compiler fetches a field from the kernarg
+// segment where it is used (s_load, per unit) and the pass loop has that many more scalar registers; by value every field
+// sits in a scalar register from the first instruction on.  Same results, different register allocation -- measured on
+// one box, interleaved: raw-rate kernel 20.46 ms by reference against 21.2 by value, 252 kS/s kernel 77.6 against 73.9
+// (DESIGN.md tuning log).  Each kernel gets the form it is faster with.
+template <bool RAW, int NCH, int PFD, bool NT, int S0, typename ARGS>
+__device__ __forceinline__ void cascade_wave_main(ARGS a)
 {
     __shared__ CascadeLds<NCH> lds;
     const int lane = threadIdx.x;
@@ -163,6 +218,9 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
     // 252 kS/s input: the lane holds samples 4*lane .. 4*lane+3 = phases 4*(lane & 1) + s of entry XH + (lane >> 1)
     double2 *xw4 = &lds.X[(lane & 1) * 4 * XS + XH + half];
     static_assert(NVX_UNIT_SPLIT == 1 || NVX_UNIT_SPLIT == 3, "a unit must end with all pending buffers empty");
+    static_assert(S0 == 1 || (S0 == 3 && RAW), "the third-order stage 0 belongs to the raw-rate kernels");
+    Stage0Cic3 s0;
+    if (S0 == 3) s0.init(lane);
     const int n_units = a.n_streams * a.n_frames * NVX_UNIT_SPLIT;
 
     for (;;) {
@@ -228,12 +286,19 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         NVX_WAVE_LDS_FENCE();
         if (!preroll) cw.state_in(st_in); else cw.state_zero();
         NVX_WAVE_LDS_FENCE();
+        if (S0 == 3) {
+            // the two blocks in front of the unit: (C, t) of the predecessor's last lane pair, or silence in front of a pre-roll
+            unsigned long long ct = 0;
+            if (!preroll && s0.last_pair)
+                ct = __hip_atomic_load((const unsigned long long *)(st_in + NVX_CASCADE_STATE_ENTRIES - 1) + (lane & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s0.c_prev = (int)(unsigned)ct; s0.t_prev = (int)(unsigned)(ct >> 32);
+        }
 
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
             if (RAW) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) xw[j * 8] = stage0_component(pf[j], odd);   // +4 double2 entries per load
+                for (int j = 0; j < 8; j++) xw[j * 8] = (S0 == 3) ? s0.step(pf[j]) : stage0_component(pf[j], odd);   // +4 double2 entries per load
             } else {
                 const uint32_t w[4] = { pf[0].x, pf[0].y, pf[0].z, pf[0].w };
 #pragma unroll
@@ -269,7 +334,12 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
         // ------------------------------------------------------ state out
         // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
-        if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) cw.state_out(st);
+        if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) {
+            cw.state_out(st);
+            if (S0 == 3 && s0.last_pair)
+                __hip_atomic_store((unsigned long long *)(st + NVX_CASCADE_STATE_ENTRIES - 1) + (lane & 1),
+                                   (unsigned long long)(unsigned)s0.c_prev | ((unsigned long long)(unsigned)s0.t_prev << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // publish: the state stores (write-through, sc1) have completed at device level once vmcnt is 0; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef NVX_HANDOFF_FENCES
@@ -280,6 +350,23 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
     }
 }
 
+template <bool RAW, int NCH, int PFD, bool NT>
+__global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
+{
+    if (RAW) cascade_wave_main<RAW, NCH, PFD, NT, 1, const nvx_cascade_args &>(a);
+    else cascade_wave_main<RAW, NCH, PFD, NT, 1, const nvx_cascade_args>(a);
+}
+
+// The raw-rate kernels with the third-order stage 0 (shipped configuration only: one pass of prefetch, nt loads).
+// The single-chain one is held to 168 VGPRs (it would take 171: two waves per SIMD instead of the three that make up
+// the 11 per CU its LDS allows); the compiler finds the three registers without spilling.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void nvx_fir_cascade_cic3_1(nvx_cascade_args a) { cascade_wave_main<true, 1, 1, true, 3, const nvx_cascade_args &>(a); }
+__global__ __launch_bounds__(64) void nvx_fir_cascade_cic3_2(nvx_cascade_args a) { cascade_wave_main<true, 2, 1, true, 3, const nvx_cascade_args &>(a); }
+
+template <bool RAW, int NCH, int PFD, bool NT, int S0> struct CascadeKernel { static constexpr auto fn = nvx_fir_cascade<RAW, NCH, PFD, NT>; };
+template <> struct CascadeKernel<true, 1, 1, true, 3> { static constexpr auto fn = nvx_fir_cascade_cic3_1; };
+template <> struct CascadeKernel<true, 2, 1, true, 3> { static constexpr auto fn = nvx_fir_cascade_cic3_2; };
+
 // ===========================================================================
 // launcher (C linkage, called from the host runtime)
 // ===========================================================================
@@ -287,7 +374,7 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 // tuning switches for A/B runs (defaults are the shipped configuration; read once per process)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
-template <bool RAW, int NCH, int PFD, bool NT>
+template <bool RAW, int NCH, int PFD, bool NT, int S0 = 1>
 static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
 {
     // persistent grid: as many single-wave workgroups as the device of this launch holds at once (cached per device:
@@ -304,7 +391,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
         if (!cached) {
             int cus = 0, per_cu = 0;
             e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nvx_fir_cascade<RAW, NCH, PFD, NT>, 64, 0);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, CascadeKernel<RAW, NCH, PFD, NT, S0>::fn, 64, 0);
             if (e != hipSuccess) return e;
             const int cap = env_int("NVX_WAVES_PER_CU", 0);
             if (cap > 0 && cap < per_cu) per_cu = cap;
@@ -326,7 +413,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     nvx_cascade_args args = *a;
     static const int force = env_int("NVX_INDEPENDENT", -1);
     args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames * NVX_UNIT_SPLIT > 1);
-    hipLaunchKernelGGL((nvx_fir_cascade<RAW, NCH, PFD, NT>), dim3(grid), dim3(64), 0, s, args);
+    hipLaunchKernelGGL((CascadeKernel<RAW, NCH, PFD, NT, S0>::fn), dim3(grid), dim3(64), 0, s, args);
     return hipGetLastError();
 }
 
@@ -340,6 +427,8 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
 #define NVX_CASE(R, C) ( \
         pfd == 2 ? (nt ? launch_cascade_as<R, C, 2, true>(a, s) : launch_cascade_as<R, C, 2, false>(a, s)) \
                  : (nt ? launch_cascade_as<R, C, 1, true>(a, s) : launch_cascade_as<R, C, 1, false>(a, s)))
+    // the third-order stage 0 exists in the shipped configuration only (one pass of prefetch, nt loads)
+    if (raw && a->stage0_order == 3) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 3>(a, s) : launch_cascade_as<true, 2, 1, true, 3>(a, s);
     if (raw) return nch == 1 ? NVX_CASE(true, 1) : NVX_CASE(true, 2);
     return nch == 1 ? NVX_CASE(false, 1) : NVX_CASE(false, 2);
 #undef NVX_CASE

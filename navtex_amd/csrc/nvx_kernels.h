@@ -33,8 +33,9 @@
 #define NVX_CASCADE_CTRL_INTS 4           /* [0] work-queue counter, [1] status (non-zero = spin timeout),  */
                                          /* [2] polls spent waiting for a predecessor, [3] units that waited */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
- * outputs and 70 FIR2 outputs, all fp64 pairs                                 */
-#define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70))
+ * outputs and 70 FIR2 outputs, all fp64 pairs; last entry: the third-order stage 0's
+ * two blocks of history as four integers (C_I | t_I << 32, C_Q | t_Q << 32)     */
+#define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70) + 1)
 #define NVX_CASCADE_STATE_BYTES   (NVX_CASCADE_STATE_ENTRIES * 16)
 #define NVX_DEMOD_DOUBLES (8 + 8 + 8 + 567) /* per slot, contiguous: last 4 IQ, dphi, class sums, |corr| */
 #define NVX_DEMOD_INTS    5
@@ -57,6 +58,7 @@ typedef struct {
     int *done;                 /* = queue + 2: frames completed per stream             */
     int independent;           /* set by the launcher: units do not wait for their predecessor (pre-roll instead) */
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid; <0 = that many fewer than fit */
+    int stage0_order;          /* raw-rate input: 3 = third-order stage 0, anything else = integrate-and-dump     */
 } nvx_cascade_args;
 
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares

@@ -47,6 +47,37 @@ void nvxo_stage0(const int16_t *raw, size_t n_out, int16_t *out)
     }
 }
 
+/* Third-order form: three cascaded 8-sample boxcars, decimated by 8 (a CIC^3 written as the 22-tap FIR it equals).
+ * hist14: the 14 raw samples in front of raw[0] (oldest first; NULL = silence), replaced by the last 14 of this call. */
+static const int32_t NVXO_CIC3_W[22] = { 1, 3, 6, 10, 15, 21, 28, 36, 42, 46, 48, 48, 46, 42, 36, 28, 21, 15, 10, 6, 3, 1 };
+
+void nvxo_stage0_cic3(const int16_t *raw, size_t n_out, int16_t *hist14, int16_t *out)
+{
+    for (size_t m = 0; m < n_out; m++) {
+        int32_t si = 256, sq = 256;                              /* + 256: round half up before >> 9 */
+        for (int j = 0; j < 22; j++) {
+            const long n = (long)(NVXO_D0 * m) + 7 - j;          /* newest sample first, as the definition reads */
+            int32_t xi = 0, xq = 0;
+            if (n >= 0) { xi = raw[2 * n]; xq = raw[2 * n + 1]; }
+            else if (hist14) { xi = hist14[2 * (14 + n)]; xq = hist14[2 * (14 + n) + 1]; }
+            si += NVXO_CIC3_W[j] * xi;
+            sq += NVXO_CIC3_W[j] * xq;
+        }
+        out[2 * m]     = (int16_t)((si >= 0) ? (si >> 9) : -((-si + 511) >> 9));      /* floor */
+        out[2 * m + 1] = (int16_t)((sq >= 0) ? (sq >> 9) : -((-sq + 511) >> 9));
+    }
+    if (hist14) {
+        const size_t n_raw = n_out * NVXO_D0;
+        int16_t keep[28];
+        for (int i = 0; i < 14; i++) {
+            const long n = (long)n_raw - 14 + i;
+            if (n >= 0) { keep[2 * i] = raw[2 * n]; keep[2 * i + 1] = raw[2 * n + 1]; }
+            else { keep[2 * i] = hist14[2 * (14 + n)]; keep[2 * i + 1] = hist14[2 * (14 + n) + 1]; }
+        }
+        memcpy(hist14, keep, sizeof keep);
+    }
+}
+
 /* ========================================================================== */
 /* wideband channeliser (build-owned, no reference counterpart)               */
 /* ========================================================================== */
@@ -615,6 +646,7 @@ struct nvxo_pipe {
     pipe_chain ch[2];
     v2d *y1, *y2, *y3; size_t cap1;
     int16_t *s0; size_t cap0;
+    int stage0_order; int16_t hist0[28];      /* raw-rate front end: 1 = integrate-and-dump, 3 = third-order form + its history */
 };
 
 nvxo_pipe *nvxo_pipe_new(int chain_mask, int freq0, int freq1, nvxo_msg_cb cb, void *user)
@@ -706,13 +738,16 @@ void nvxo_pipe_push(nvxo_pipe *p, const int16_t *iq, size_t n)
     }
 }
 
+void nvxo_pipe_set_stage0(nvxo_pipe *p, int order) { p->stage0_order = (order == 3) ? 3 : 1; }
+
 void nvxo_pipe_push_raw(nvxo_pipe *p, const int16_t *raw, size_t n_out)
 {
     const size_t BLK = 2520 * 8;
     if (p->cap0 < BLK) { p->cap0 = BLK; p->s0 = realloc(p->s0, BLK * 2 * sizeof(int16_t)); }
     while (n_out) {
         size_t m = n_out < BLK ? n_out : BLK;
-        nvxo_stage0(raw, m, p->s0);
+        if (p->stage0_order == 3) nvxo_stage0_cic3(raw, m, p->hist0, p->s0);
+        else nvxo_stage0(raw, m, p->s0);
         pipe_block(p, p->s0, m);
         raw += 2 * m * NVXO_D0; n_out -= m;
     }
@@ -744,7 +779,7 @@ double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int cha
         const long s = job % (long)nstreams;            /* the same sample, `repeat` times over */
         nvxo_pipe *p = nvxo_pipe_new(chain_mask, 518, 490, NULL, NULL);
         nvxo_pipe_set_charlayer(p, 0);
-        if (raw) nvxo_pipe_push_raw(p, iq + (size_t)s * stride, n);
+        if (raw) { nvxo_pipe_set_stage0(p, raw == 3 ? 3 : 1); nvxo_pipe_push_raw(p, iq + (size_t)s * stride, n); }
         else     nvxo_pipe_push(p, iq + (size_t)s * stride, n);
         if (bits_out && job < (long)nstreams) {
             size_t nb; const char *b = nvxo_pipe_bits(p, (chain_mask & 1) ? 0 : 1, &nb);

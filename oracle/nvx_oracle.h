@@ -38,6 +38,12 @@ extern "C" {
 /* ---- build-owned stage 0: integrate-and-dump /8 with round-half-up --------
  * out[m] = (sum_{j<8} raw[8m+j] + 4) >> 3, per component, arithmetic shift.  */
 void nvxo_stage0(const int16_t *raw_iq, size_t n_out, int16_t *out_iq);
+/* ---- build-owned stage 0, third-order form (three cascaded 8-sample boxcars, decimated by 8):
+ * out[m] = (sum_{j<22} w[j] * raw[8m+7-j] + 256) >> 9,  w = (1,1,..,1)^*3 = 1 3 6 10 15 21 28 36 42 46 48 48 46 ... 3 1
+ * (sum 512), per component, floor shift; raw[n<0] = hist14 (the 14 samples in front, oldest first; NULL = silence),
+ * which the call replaces by the last 14 samples it saw.  Alias rejection at the NAVTEX offsets (+-14 kHz +- 85 Hz
+ * around multiples of 252 kHz): 3 x the boxcar's 25.4 dB = 76 dB.                                                    */
+void nvxo_stage0_cic3(const int16_t *raw_iq, size_t n_out, int16_t *hist14, int16_t *out_iq);
 
 /* ---- build-owned wideband front-end (no reference counterpart):
  * 8-channel maximally decimated polyphase channeliser, integer arithmetic only.
@@ -102,6 +108,8 @@ void       nvxo_pipe_free(nvxo_pipe *p);
 void       nvxo_pipe_push(nvxo_pipe *p, const int16_t *iq252, size_t n);
 /* push n_out*8 complex samples at 2.016 MS/s through stage 0 first */
 void       nvxo_pipe_push_raw(nvxo_pipe *p, const int16_t *raw_iq, size_t n_out);
+/* which stage 0 push_raw applies: 1 (default) = integrate-and-dump, 3 = third-order form (history carried in the pipe) */
+void       nvxo_pipe_set_stage0(nvxo_pipe *p, int order);
 /* bits decoded so far on chain c (NUL-terminated, grows) */
 const char *nvxo_pipe_bits(nvxo_pipe *p, int chain, size_t *n);
 /* optional seam taps: append every y3 sample of chain c to a caller buffer */
@@ -110,7 +118,7 @@ void       nvxo_pipe_tap_y3(nvxo_pipe *p, int chain, double *buf, size_t cap_pai
 void       nvxo_pipe_set_charlayer(nvxo_pipe *p, int enabled);
 
 /* ---- timed CPU baseline: nstreams independent streams, OpenMP over streams.
- * raw=1: iq is [nstreams][n*8] at 2.016 MS/s (stage 0 included), else
+ * raw=1: iq is [nstreams][n*8] at 2.016 MS/s (stage 0 included; raw=3: its third-order form), else
  * [nstreams][n] at 252 kS/s.  The whole sample is processed `repeat` times
  * (fresh state each time) so a bounded sample can fill a timing window.
  * Returns seconds; fills bits_out[nstreams][cap]

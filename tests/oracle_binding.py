@@ -31,6 +31,7 @@ MSG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int)
 _vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
 for name, res, args in [
     ("nvxo_stage0", None, [_vp, _sz, _vp]), ("nvxo_channelise", None, [_vp, _sz, _vp, _vp]),
+    ("nvxo_stage0_cic3", None, [_vp, _sz, _vp, _vp]), ("nvxo_pipe_set_stage0", None, [_vp, _i]),
     ("nvxo_fir1", _sz, [_vp, _sz, _vp]), ("nvxo_mix", None, [_vp, _sz, _i, _vp]),
     ("nvxo_fir2", _sz, [_vp, _sz, _vp]), ("nvxo_fir3", _sz, [_vp, _sz, _vp]),
     ("nvxo_mixer_table", None, [_vp, _vp]), ("nvxo_bitfilter_table", None, [_vp, _vp]),
@@ -58,6 +59,17 @@ def stage0(raw_iq: np.ndarray) -> np.ndarray:
     n_out = raw_iq.shape[0] // 8
     out = np.empty((n_out, 2), dtype=np.int16)
     L.nvxo_stage0(_p(raw_iq), n_out, _p(out))
+    return out
+
+
+def stage0_cic3(raw_iq: np.ndarray, hist14: np.ndarray | None = None) -> np.ndarray:
+    """Third-order stage 0; hist14 ([14, 2] int16, the samples in front; updated in place) or None = silence, not carried."""
+    raw_iq = np.ascontiguousarray(raw_iq, dtype=np.int16).reshape(-1, 2)
+    n_out = raw_iq.shape[0] // 8
+    out = np.empty((n_out, 2), dtype=np.int16)
+    if hist14 is not None:
+        assert hist14.dtype == np.int16 and hist14.shape == (14, 2) and hist14.flags.c_contiguous
+    L.nvxo_stage0_cic3(_p(raw_iq), n_out, _p(hist14) if hist14 is not None else None, _p(out))
     return out
 
 
@@ -177,6 +189,9 @@ class Pipe:
         assert raw.shape[0] % 8 == 0
         L.nvxo_pipe_push_raw(self._h, _p(raw), raw.shape[0] // 8)
 
+    def set_stage0(self, order: int) -> None:
+        L.nvxo_pipe_set_stage0(self._h, order)
+
     def bits(self, chain: int = 0) -> str:
         return L.nvxo_pipe_bits(self._h, chain, None).decode("ascii")
 
@@ -192,7 +207,8 @@ class Pipe:
 
 def bench(iq: np.ndarray, nstreams: int, n: int, raw: bool, chain_mask: int, nthreads: int, want_bits: bool = False,
           repeat: int = 1):
-    """Timed CPU baseline; iq is [nstreams, n*(8 if raw else 1), 2] int16.  Returns (seconds, bits list)."""
+    """Timed CPU baseline; iq is [nstreams, n*(8 if raw else 1), 2] int16 (raw: False / True = stage 0 as integrate-and-dump /
+    3 = its third-order form).  Returns (seconds, bits list)."""
     iq = np.ascontiguousarray(iq, dtype=np.int16)
     cap = n // 2520 + 64
     buf = C.create_string_buffer(nstreams * cap) if want_bits else None

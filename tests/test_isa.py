@@ -49,7 +49,7 @@ def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
     assert "s_barrier" not in main                                     # single-wave workgroups: compiler fences only
 
 
-@pytest.mark.parametrize("inst", ["ILb1ELi1ELi1ELb1", "ILb1ELi2ELi1ELb1", "ILb0ELi1ELi1ELb1", "ILb0ELi2ELi1ELb1"])
+@pytest.mark.parametrize("inst", ["ILb1ELi1ELi1ELb1", "ILb1ELi2ELi1ELb1", "ILb0ELi1ELi1ELb1", "ILb0ELi2ELi1ELb1", "_cic3_1", "_cic3_2"])
 def test_unit_hand_over_is_fence_free_and_device_coherent(isa, inst):
     """The hand-over of filter state between the units of a stream (nvx_cascade.hip, state_load / state_store / done[])
     rests on per-instruction device coherence instead of cache-wide fences.  What the hardware needs for that
@@ -65,7 +65,7 @@ def test_unit_hand_over_is_fence_free_and_device_coherent(isa, inst):
     assert not any(l.startswith(("buffer_wbl2", "buffer_inv")) for l in lines)
     ld8 = [l for l in lines if l.startswith("global_load_dwordx2")]
     st8 = [l for l in lines if l.startswith("global_store_dwordx2")]
-    n_chains = 2 if "Li2E" in inst else 1
+    n_chains = 2 if ("Li2E" in inst or inst.endswith("_2")) else 1
     n_state = 2 * (1 + 3 * n_chains)                      # double2 = two 8-byte accesses: 252 kS/s window + per chain U, Y2, Y2 tail
     assert len(ld8) >= n_state and all(l.endswith(" sc1") for l in ld8), ld8
     assert sum(l.endswith(" sc1") for l in st8) >= n_state
@@ -85,7 +85,21 @@ def test_unit_hand_over_is_fence_free_and_device_coherent(isa, inst):
     assert after == [], after
 
 
+def test_third_order_stage0_code_shape_and_occupancy(isa):
+    """The third-order stage 0 (nvx_cascade.hip, Stage0Cic3): per 1-KiB load four v_perm, twelve v_dot2, four wave
+    rotations; no fused multiply-add behind it either; and the single-chain kernel stays within the 168 VGPRs that three
+    waves per SIMD -- the 11 per CU its LDS allows -- can have."""
+    kernels, meta = isa
+    body = next(v for k, v in kernels.items() if "nvx_fir_cascade_cic3_1" in k)
+    assert len(re.findall(r"v_dot2c?_i32_i16", body)) == 8 * 12
+    assert body.count("wave_ror:1") == 8 * 4 and body.count("v_perm_b32") == 8 * 4
+    assert not re.search(r"v_fma_f64|v_fmac_f64", body) and "scratch_" not in body
+    assert len(re.findall(r"global_load_dwordx4 .* nt", body)) >= 16
+    m = re.search(r"\.name:\s+_Z22nvx_fir_cascade_cic3_1.*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", meta, re.S)
+    assert m and int(m.group(1)) <= 168 and int(m.group(2)) == 0, m and m.groups()
+
+
 def test_no_kernel_spills(isa):
     _, meta = isa
     sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", meta)]
-    assert len(sizes) >= 16 + 4 and all(s == 0 for s in sizes), sizes      # 16 cascade instantiations + demod x2, channeliser, generator
+    assert len(sizes) >= 18 + 4 and all(s == 0 for s in sizes), sizes      # 16 + 2 cascade kernels + demod x2, channeliser, generator

@@ -1,0 +1,238 @@
+"""The third-order stage 0 (nvx_config.stage0_order = 3): three cascaded 8-sample boxcars decimated by 8.
+Build-owned definition (the reference starts at 252 kS/s: receiver/capt_sched.c:31-34), so the chain of evidence is
+    numpy restatement of the definition  ==  oracle (nvxo_stage0_cic3)            CPU tests below
+    oracle stage 0 -> oracle pipeline (pinned to the compiled reference)  ==  HIP path    GPU tests below, bit for bit
+plus what makes it worth having: its alias rejection at the NAVTEX offsets."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import signals
+
+ROOT = Path(__file__).resolve().parent.parent
+W3 = np.convolve(np.convolve(np.ones(8, dtype=np.int64), np.ones(8, dtype=np.int64)), np.ones(8, dtype=np.int64))
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the definition
+def test_weights_are_three_boxcars():
+    assert W3.tolist() == [1, 3, 6, 10, 15, 21, 28, 36, 42, 46, 48, 48, 46, 42, 36, 28, 21, 15, 10, 6, 3, 1] and W3.sum() == 512
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_oracle_matches_the_written_definition(oracle, seed):
+    """out[m] = floor((sum_j w[j] x[8m+7-j] + 256) / 512), x[n<0] = 0, on full-scale noise (extremes included)."""
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(-32768, 32768, size=(8 * 700, 2), dtype=np.int16)
+    raw[100:140] = 32767; raw[300:340] = -32768                                # rails: the result must stay in int16
+    x = np.vstack([np.zeros((14, 2), np.int64), raw.astype(np.int64)])
+    want = np.empty((700, 2), np.int64)
+    for m in range(700):
+        seg = x[14 + 8 * m + 7 - 21: 14 + 8 * m + 8][::-1]                     # newest first
+        want[m] = (seg * W3[:, None]).sum(0) + 256
+    want = np.floor_divide(want, 512)
+    got = oracle.stage0_cic3(raw)
+    assert np.array_equal(got.astype(np.int64), want)
+    assert got.max() == 32767 and got.min() == -32768
+
+
+def test_oracle_history_makes_chunking_invisible(oracle):
+    rng = np.random.default_rng(5)
+    raw = rng.integers(-20000, 20000, size=(8 * 900, 2), dtype=np.int16)
+    whole = oracle.stage0_cic3(raw)
+    h = np.zeros((14, 2), np.int16)
+    cuts = [0, 8, 16, 24, 800, 808, 4000, 7200]
+    parts = [oracle.stage0_cic3(raw[a:b], h) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.vstack(parts), whole)
+    assert np.array_equal(h, raw[-14:])
+
+
+def test_alias_rejection_at_the_navtex_offsets(oracle):
+    """What folds onto a carrier at +-14 kHz comes from m * 252 kHz +- 14 kHz.  Integrate-and-dump: 25 dB at the worst
+    image; third-order form: three times that.  Pass band (the carrier itself) unchanged to 0.1 dB."""
+    fs, n = 2016000, 8 * 30000
+    t = np.arange(n)
+
+    def level(fn, f):
+        z = np.round(20000 * np.exp(2j * np.pi * f * t / fs))
+        y = fn(np.stack([z.real, z.imag], 1).astype(np.int16)).astype(float)
+        return 20 * np.log10(max(np.sqrt((y[200:] ** 2).sum(1).mean()), 1e-9) / 20000)
+
+    assert abs(level(oracle.stage0_cic3, 14000)) < 0.15 and abs(level(oracle.stage0_cic3, -14085)) < 0.15
+    worst_box = max(level(oracle.stage0, f) for f in (252000 + 14000, 252000 - 14000, -252000 + 14085, 504000 - 14000))
+    worst_cic = max(level(oracle.stage0_cic3, f) for f in (252000 + 14000, 252000 - 14000, -252000 + 14085, 504000 - 14000,
+                                                            756000 + 14000, 1008000 - 14000))
+    assert -26.5 < worst_box < -24.0
+    assert worst_cic < -72.0
+
+
+def test_pipe_with_third_order_stage0_is_stage0_then_pipe(oracle, nv):
+    st = signals.stream_params(nv, 77, nv.RATE_RAW)[0]
+    raw = nv.synth_host(st, nv.RATE_RAW, 4 * nv.FRAME_RAW)
+    a = oracle.Pipe(chain_mask=1, charlayer=False); a.set_stage0(3)
+    for lo, hi in ((0, 8 * 1000), (8 * 1000, 8 * 1001), (8 * 1001, raw.shape[0])):
+        a.push_raw(raw[lo:hi])
+    b = oracle.Pipe(chain_mask=1, charlayer=False)
+    b.push(oracle.stage0_cic3(raw))
+    assert a.bits(0) == b.bits(0) and len(a.bits(0)) > 40
+    secs, bits = oracle.bench(raw[None], 1, 4 * nv.FRAME_IN, 3, 1, 1, want_bits=True)
+    assert bits[0] == a.bits(0)
+
+
+def test_config_errors_need_no_gpu(nv):
+    """stage0_order is checked before any device call: 2 is no order, 3 needs raw-rate input."""
+    from navtex_amd import _native as N
+    for kw, frag in ((dict(raw_rate=1, stage0_order=2), "stage0_order"), (dict(raw_rate=0, stage0_order=3), "raw_rate"),
+                     (dict(raw_rate=1, wideband=1, stage0_order=3), "raw_rate")):
+        cfg = N.Config()
+        nv.lib.nvx_config_default(C.byref(cfg))
+        for k, v in kw.items(): setattr(cfg, k, v)
+        h = C.c_void_p()
+        assert nv.lib.nvx_create(C.byref(cfg), C.byref(h)) == N.ERR_ARG and not h.value
+        assert frag in nv.lib.nvx_last_error().decode()
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the HIP path
+def _two_carriers(nv):
+    spb = nv.RATE_RAW // 100
+    b518 = nv.sitor_encode("ZCZC EA01\nTEST MESSAGE 123 OK\nNNNN\n", 40)
+    b490 = nv.sitor_encode("ZCZC GB42\nGALE WARNING 7/8 NW-LY.\nNNNN\n", 45)
+    return nv.make_stream([dict(freq_hz=14000, bits=b518, bit_offset=777 % spb, phase0=12345678),
+                           dict(freq_hz=-14000, bits=b490, bit_offset=1999 % spb, phase0=987654321, amplitude=6000)], seed=7, noise_amp=1500)
+
+
+@pytest.mark.gpu
+def test_y3_bitexact_and_bits_with_carried_state(nv, oracle):
+    """One stream, both chains, odd-sized pushes (several launches): the 900 S/s output carries the fp64 bit patterns of
+    oracle stage 0 -> oracle cascade, so the 22-tap sums, their two carried blocks and the rounding are the oracle's."""
+    n_frames = 5
+    iq = nv.synth_host(_two_carriers(nv), nv.RATE_RAW, n_frames * nv.FRAME_RAW)
+    iq[1000:1100] = 32767; iq[5000:5050] = -32768                              # full scale through the dot products
+    ref = oracle.Pipe(chain_mask=3, tap_y3=n_frames * nv.FRAME_Y3, charlayer=False)
+    ref.set_stage0(3)
+    ref.push_raw(iq)
+    box = oracle.Pipe(chain_mask=3, charlayer=False)
+    box.push_raw(iq)
+    with nv.Pipeline(n_streams=1, raw_rate=True, max_frames=2, push_mode=True, char_layer=False, stage0_order=3) as p:
+        p.enable_debug(True)
+        rng = np.random.default_rng(11)
+        pos, y3 = 0, {0: [], 1: []}
+        while pos < iq.shape[0]:
+            m = int(min(iq.shape[0] - pos, rng.integers(1, 2 * nv.FRAME_RAW)))
+            p.push(0, iq[pos:pos + m]); pos += m
+        p.flush()
+        for c in (0, 1):
+            assert p.bits(0, c) == ref.bits(c)
+    # one launch: the whole y3 record
+    with nv.Pipeline(n_streams=1, raw_rate=True, max_frames=n_frames, push_mode=True, char_layer=False, stage0_order=3) as p:
+        p.enable_debug(True)
+        p.push(0, iq); p.flush()
+        for c in (0, 1):
+            assert np.array_equal(_u64(p.debug_y3(0, c)), _u64(ref.y3(c))), f"chain {c}: not bit-exact"
+    assert ref.bits(0) != "" and len(ref.bits(0)) == len(box.bits(0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_randomized_configurations(nv, oracle, seed):
+    """Random stream counts, chain masks (both kernels), carrier levels up to the rails, launch partitions with carried
+    state; every chain of every stream against the oracle."""
+    rng = np.random.default_rng(900 + seed)
+    n_streams = int(rng.integers(1, 30))
+    n_frames = int(rng.integers(3, 7))
+    masks = [int(rng.choice([1, 2, 3])) for _ in range(n_streams)]
+    if seed % 2: masks = [m if m != 3 else 2 for m in masks]
+    spb = nv.RATE_RAW // 100
+    iqs = []
+    for s in range(n_streams):
+        carriers = [dict(freq_hz=f + int(rng.integers(-10, 11)), bits=nv.sitor_encode(signals.stream_text(7 * seed + s), 8),
+                         bit_offset=int(rng.integers(0, spb)), phase0=int(rng.integers(0, 2**32)), amplitude=int(rng.integers(1500, 14000)))
+                    for c, f in ((0, 14000), (1, -14000)) if (masks[s] >> c) & 1 or rng.random() < 0.3]
+        iqs.append(nv.synth_host(nv.make_stream(carriers, seed=5000 * seed + s, noise_amp=int(rng.integers(0, 6000))), nv.RATE_RAW, n_frames * nv.FRAME_RAW))
+    pitch = n_frames * nv.FRAME_RAW + 4 * int(rng.integers(0, 64))
+    buf = nv.DeviceBuffer(n_streams * pitch * 4)
+    for s in range(n_streams): buf.upload(iqs[s], offset=s * pitch * 4)
+    max_frames = int(rng.integers(1, n_frames + 1))
+    with nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_masks=masks, max_frames=max_frames, char_layer=False, stage0_order=3) as p:
+        f0 = 0
+        while f0 < n_frames:
+            k = int(min(n_frames - f0, rng.integers(1, max_frames + 1)))
+            p.process_resident(buf, pitch, f0, k); f0 += k
+        p.fetch()
+        for s in range(n_streams):
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False); ref.set_stage0(3)
+            ref.push_raw(iqs[s])
+            for c in range(2):
+                assert p.bits(s, c) == (ref.bits(c) if (masks[s] >> c) & 1 else ""), f"seed {seed} stream {s} chain {c}"
+    buf.free()
+
+
+@pytest.mark.gpu
+def test_hand_over_form_more_streams_than_resident_waves(nv, oracle):
+    """3000 streams x 3 frames in launches of 2 + 1: more streams than the chip holds waves, so the frames of a stream go
+    from unit to unit through the state block (the two carried blocks of stage 0 with them), and from launch to launch.
+    A sample of streams against the oracle; twins identical."""
+    S, F = 3000, 3
+    streams = [signals.stream_params(nv, 20000 + s, nv.RATE_RAW)[0] for s in range(S)]
+    streams[1777] = streams[5]
+    pitch = F * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(S * pitch * 4)
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=2, char_layer=False, stage0_order=3) as p:
+        p.process_resident(buf, pitch, 0, 2)
+        p.process_resident(buf, pitch, 2, 1)
+        p.fetch()
+        polls, units, launches = p.wait_stats()
+        assert launches == 2
+        assert p.bits(1777, 0) == p.bits(5, 0)
+        for s in (0, 1, 5, 999, 1500, 2047, 2048, 2815, 2816, 2999):
+            iq = buf.download(pitch * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+            ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.set_stage0(3)
+            ref.push_raw(iq)
+            assert p.bits(s, 0) == ref.bits(0), f"stream {s}"
+    buf.free()
+
+
+@pytest.mark.gpu
+def test_both_unit_forms_agree(nv, tmp_path):
+    """Hand-over and independent units (nine-pass pre-roll in front of silence for stage 0's history) forced in a
+    subprocess each: identical 900 S/s output and bits."""
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv, signals
+h = hashlib.sha256()
+for masks in ([1, 2, 1], [3, 1, 3]):
+    streams = [signals.stream_params(nv, 800 + s, nv.RATE_RAW)[0] for s in range(3)]
+    pitch = 8 * nv.FRAME_RAW
+    buf = nv.DeviceBuffer(3 * pitch * 4)
+    nv.synth_device(streams, nv.RATE_RAW, pitch, buf, pitch)
+    with nv.Pipeline(n_streams=3, raw_rate=True, chain_masks=masks, max_frames=5, char_layer=False, stage0_order=3) as p:
+        p.enable_debug(True)
+        p.process_resident(buf, pitch, 0, 5); p.fetch()
+        for s in range(3):
+            for c in range(2):
+                if (masks[s] >> c) & 1: h.update(p.debug_y3(s, c).tobytes())
+        p.process_resident(buf, pitch, 5, 3); p.fetch()
+        for s in range(3):
+            for c in range(2): h.update(p.bits(s, c).encode())
+    buf.free()
+print(h.hexdigest())
+''')
+    digests = []
+    for mode in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, NVX_INDEPENDENT=mode))
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] and len(digests[0]) == 64
