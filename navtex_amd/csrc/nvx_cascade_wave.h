@@ -84,6 +84,16 @@ __device__ __forceinline__ double dpp_swap_pairs_f64(double v)
 #define NVX_F1_AHEAD 3                    /* groups in flight ahead of the arithmetic */
 #endif
 #define NVX_F23_AHEAD 12                  /* FIR2 / FIR3: taps read ahead */
+/* FIR2 / FIR3 tap i: a plain literal.  The compiler creates all 118 at kernel entry, parks most of them in VGPR lanes
+ * (70 "SGPR spills") and fetches a tap back with two v_readlane in front of its multiply.  -DNVX_TAPS_INPLACE creates every
+ * tap where it is used instead (two s_mov_b32, nvx_device.h): no spill, no v_readlane, 212 vector instructions fewer in
+ * the pass loop's code -- and measured no faster (Variant A 75.3 vs 74.9-79 ms) or slower (fused wideband 19.6 vs 18.5 ms,
+ * raw 21.0 vs 20.75): the count of instructions a wave issues is what it was, and they are 8 bytes each.  Kept for A/B. */
+#ifdef NVX_TAPS_INPLACE
+#define NVX_TAP(H, i) (nvx_scalar_f64<nvx_lo32(H[i]), nvx_hi32(H[i])>())
+#else
+#define NVX_TAP(H, i) (H[i])
+#endif
 __device__ __forceinline__ constexpr int f1_offset(int j)
 {
     const int t = 7 - j, r = t & 7, fl = (t - r) / 8;
@@ -308,11 +318,11 @@ struct CascadeWave {
                 double xs2[NVX_T2], acc = 0.0;                // reads run ahead of the arithmetic, as in FIR1
 #pragma unroll
                 for (int i = 0; i < NVX_F23_AHEAD; i++) xs2[i] = ub[2 * (52 - i)];
-#pragma unroll
-                for (int i = 0; i < NVX_T2; i++) {
-                    if (i + NVX_F23_AHEAD < NVX_T2) { NVX_PIN_AFTER(acc); xs2[i + NVX_F23_AHEAD] = ub[2 * (52 - (i + NVX_F23_AHEAD))]; }
-                    acc += NVX_H2[i] * xs2[i];
-                }
+                nvx_static_for<0, NVX_T2>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i + NVX_F23_AHEAD < NVX_T2) { NVX_PIN_AFTER(acc); xs2[i + NVX_F23_AHEAD] = ub[2 * (52 - (i + NVX_F23_AHEAD))]; }
+                    acc += NVX_TAP(NVX_H2, i) * xs2[i];
+                });
                 if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds->Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
             }
             NVX_WAVE_LDS_FENCE();
@@ -346,11 +356,11 @@ struct CascadeWave {
                     double xs3[NVX_T3], acc = 0.0;
 #pragma unroll
                     for (int i = 0; i < NVX_F23_AHEAD; i++) xs3[i] = yb[2 * (79 - i)];
-#pragma unroll
-                    for (int i = 0; i < NVX_T3; i++) {
-                        if (i + NVX_F23_AHEAD < NVX_T3) { NVX_PIN_AFTER(acc); xs3[i + NVX_F23_AHEAD] = yb[2 * (79 - (i + NVX_F23_AHEAD))]; }
-                        acc += NVX_H3[i] * xs3[i];
-                    }
+                    nvx_static_for<0, NVX_T3>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i + NVX_F23_AHEAD < NVX_T3) { NVX_PIN_AFTER(acc); xs3[i + NVX_F23_AHEAD] = yb[2 * (79 - (i + NVX_F23_AHEAD))]; }
+                        acc += NVX_TAP(NVX_H3, i) * xs3[i];
+                    });
                     if (emit && f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
                         double *out = (double *)(y3 + (y3_row0 + (size_t)ch * y3_cap + n3_done + f3o));
                         out[comp] = acc;

@@ -3,6 +3,7 @@
 #define NVX_DEVICE_H
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 // A single wave owns all LDS it touches; LDS instructions of one wave execute
 // in program order, so cross-lane hand-offs need no s_barrier and no waitcnt --
@@ -21,6 +22,25 @@ typedef __attribute__((address_space(3))) volatile nvx_d2 lds_vd2;          // o
 // (the empty asm is volatile, so it keeps its order against volatile accesses, and it "modifies" v).  Without it the
 // scheduler hoists every LDS read of an unrolled FIR to the top of the block and the kernel needs 140 more VGPRs.
 #define NVX_PIN_AFTER(v) asm volatile("" : "+v"(v))
+
+// A 64-bit constant in a scalar register pair, materialised (two s_mov_b32) where it is used; the asm is volatile so
+// that it stays there.  Used by the -DNVX_TAPS_INPLACE build of the cascade (nvx_cascade_wave.h, NVX_TAP).
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double nvx_scalar_f64()
+{
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "i"((int)LO));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "i"((int)HI));
+    return __hiloint2double((int)hi, (int)lo);
+}
+constexpr unsigned nvx_lo32(double v) { return (unsigned)__builtin_bit_cast(unsigned long long, v); }
+constexpr unsigned nvx_hi32(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32); }
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1, in order
+template <int I, int N, typename F>
+__device__ __forceinline__ void nvx_static_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); nvx_static_for<I + 1, N>(f); }
+}
 
 typedef short nvx_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal builtin needs it
