@@ -20,11 +20,14 @@ __global__ __launch_bounds__(64) void k(double *out, int iters)
     double acc0 = 1.0, acc1 = 2.0, s = 0.0;
     const lds_vdouble *p64 = (const lds_vdouble *)&lds[lane];
     const lds_vd2 *p128 = (const lds_vd2 *)&lds[2 * lane];
+    typedef __attribute__((address_space(3))) volatile short lds_vshort;
+    const lds_vshort *p16 = (const lds_vshort *)((const short *)lds + lane);     // KIND 2: a lane pair shares a dword (packed int16 I | Q)
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             double v;
             if (KIND == 0) v = p64[64 * (j % 8)];
+            else if (KIND == 2) v = (double)(int)p16[128 * (j % 8)];          // ds_read_i16 + v_cvt_f64_i32
             else { d2 t = p128[64 * (j % 4)]; v = t.x + 0 * t.y; }
             s += v;                                   // one dependent add per read keeps the read alive
 #pragma unroll
@@ -64,6 +67,9 @@ int main()
     run<0, 9, 13888>("ds_read_b64 + 10 fp64", 11, d);
     run<1, 3, 13888>("ds_read_b128 + 4 fp64 (round 1: 4)", 11, d);
     run<1, 9, 13888>("ds_read_b128 + 10 fp64", 11, d);
+    run<2, 0, 13888>("ds_read_i16 + cvt + 1 fp64", 11, d);
+    run<2, 3, 13888>("ds_read_i16 + cvt + 4 fp64 (int16 window)", 11, d);
+    run<2, 3, 10000>("ds_read_i16 + cvt + 4 fp64 (int16 window)", 15, d);
     run<0, 3, 10000>("ds_read_b64 + 4 fp64", 16, d);
     run<0, 3, 20000>("ds_read_b64 + 4 fp64", 8, d);
     run<0, 3, 40000>("ds_read_b64 + 4 fp64", 4, d);
