@@ -41,3 +41,19 @@ def test_capture_ring_is_clean_under_tsan(tmp_path):
                          env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "tsan capture ok" in out.stdout and "dropped 0 " not in out.stdout      # overruns really happened
+
+
+def test_group_is_clean_under_tsan(tmp_path):
+    """ThreadSanitizer over the multi-device group (nvx_group.cpp): four member workers with their job queues, a thread
+    pushing into streams of every member, a thread polling bits, launches and fetches from the main thread; the handle
+    behind every member is a stand-in with the real locking contract (tests/harness/tsan_group.cpp).  No race; every
+    message exactly once, global stream ids, member order within a fetch; a member's failure is reported with its name."""
+    exe = tmp_path / "tsan_group"
+    csrc = ROOT / "navtex_amd" / "csrc"
+    subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    f"-I{ROOT / 'include'}", f"-I{csrc}", str(ROOT / "tests" / "harness" / "tsan_group.cpp"),
+                    str(csrc / "nvx_group.cpp"), "-o", str(exe), "-lpthread"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                         env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "tsan group ok" in out.stdout
