@@ -188,6 +188,13 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // Units are handed out part-major, so a unit's predecessor was taken n_streams
 // units earlier by a workgroup that is already running: the wait cannot
 // deadlock whatever the residency, and every spin is bounded anyway.
+// r2: a unit that finds its predecessor still running does not wait for it: it
+// rebuilds the histories from the nine passes in front of it (the pre-roll of
+// the independent-unit form, +2.9 % of a unit, identical results) and only
+// PUBLISHES behind its predecessor, so the state block and done[] still advance
+// in order.  1.4 % of the units at the headline size, 10 % with 252 kS/s input;
+// cascade 20.86 -> 20.30 ms and 74.4-78.4 -> 73.7 ms (DESIGN.md tuning log).
+// NVX_DYNAMIC_PREROLL=0: such a unit waits, as in round 1.
 // Why: LDS limits residency to 11 waves per CU (2816), so 4096 equal-length
 // per-stream jobs would run as a VALU-saturated first round and a
 // latency-bound tail of 1280; frame-sized units keep every CU full to the end.
@@ -234,16 +241,17 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         const unsigned mask = a.chain_masks[stream];
 
         // independent units: rebuild the histories from the nine passes in front of the unit (nvx_kernels.h)
-        const bool preroll = a.independent && part > 0;
-        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
-        const int n_pass = pre + NVX_UNIT_PASSES;
-        // the input does not depend on the predecessor: request the first pass(es) now
-        const u32x4 *src = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) +
-                           ((size_t)part * NVX_UNIT_PASSES - (size_t)pre) * pass_stride + lane;
+        bool preroll = a.independent && part > 0;
+        // ... and so does a unit of a hand-over launch whose predecessor is still running (a.dynamic_preroll): nine passes
+        // more (2.9 % of a unit) instead of the rest of the predecessor's run time.  Same results either way
+        // (tests: the two unit forms agree bit for bit).  Such a unit owes its successor the order of the state block: it
+        // publishes only behind its predecessor (the wait moves from the start of the unit, where it costs, to its end).
+        bool late_publish = false;
+        // the input does not depend on the predecessor: request the first pass now (of the unit itself; a unit that turns
+        // out to need the pre-roll requests its real first pass again and lets this one go)
+        const u32x4 *unit0 = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + (size_t)part * NVX_UNIT_PASSES * pass_stride + lane;
         u32x4 pfA[NPF], pfB[NPF];
-        load_pass<RAW, NT>(pfA, src);
-        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
-        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
+        if (!preroll) load_pass<RAW, NT>(pfA, unit0);
 
         // ------------------------------------------------------ wait for (stream, part-1)
         if (part > 0 && !a.independent) {
@@ -253,24 +261,36 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
                 if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 d = __builtin_amdgcn_readfirstlane(d);
                 ok = d >= part;
+                if (!ok && a.dynamic_preroll) break;
                 if (!ok) __builtin_amdgcn_s_sleep(32);
             } while (!ok && ++spins < NVX_SPIN_LIMIT);
-            if (spins > 0 && lane == 0) {                // instrumentation: how often, and how long, a hand-over was waited for
-                __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (!ok) {                                   // give up loudly rather than hang the GPU
-                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+            if (!ok && a.dynamic_preroll) {
+                preroll = true; late_publish = true;
+                if (lane == 0) __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // units that found their predecessor running
+            } else {
+                if (spins > 0 && lane == 0) {                // instrumentation: how often, and how long, a hand-over was waited for
+                    __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!ok) {                                   // give up loudly rather than hang the GPU
+                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
 #ifdef NVX_HANDOFF_FENCES
-            // one agent-scope acquire per unit: the state lines may sit stale in this CU's L1
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // one agent-scope acquire per unit: the state lines may sit stale in this CU's L1
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-            asm volatile("" ::: "memory");               // the state loads below stay below the flag poll
+                asm volatile("" ::: "memory");               // the state loads below stay below the flag poll
 #endif
+            }
         }
+        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
+        const int n_pass = pre + NVX_UNIT_PASSES;
+        const u32x4 *src = unit0 - (size_t)pre * pass_stride;
+        if (preroll) load_pass<RAW, NT>(pfA, src);
+        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
+        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
 
         // ------------------------------------------------------ state in
         // A stream's first unit of a launch reads the block the previous launch left (state_in); every unit
@@ -334,6 +354,23 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         // ------------------------------------------------------ state out
         // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
+        if (late_publish) {
+            // the predecessor has to have published (state block, then done[]) before this unit's state goes on top of it
+            int spins = 0, ok = 0;
+            do {
+                int d = 0;
+                if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = __builtin_amdgcn_readfirstlane(d);
+                ok = d >= part;
+                if (!ok) __builtin_amdgcn_s_sleep(32);
+            } while (!ok && ++spins < NVX_SPIN_LIMIT);
+            if (spins > 0 && lane == 0) __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) {
+                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            asm volatile("" ::: "memory");
+        }
         if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) {
             cw.state_out(st);
             if (S0 == 3 && s0.last_pair)
@@ -413,6 +450,10 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     nvx_cascade_args args = *a;
     static const int force = env_int("NVX_INDEPENDENT", -1);
     args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames * NVX_UNIT_SPLIT > 1);
+    // hand-over launches: a unit whose predecessor is still running rebuilds its histories instead of waiting for it
+    // (NVX_DYNAMIC_PREROLL=0: it waits, as in round 1)
+    static const int dynamic = env_int("NVX_DYNAMIC_PREROLL", 1);
+    args.dynamic_preroll = dynamic != 0;
     hipLaunchKernelGGL((CascadeKernel<RAW, NCH, PFD, NT, S0>::fn), dim3(grid), dim3(64), 0, s, args);
     return hipGetLastError();
 }

@@ -59,6 +59,7 @@ typedef struct {
     int independent;           /* set by the launcher: units do not wait for their predecessor (pre-roll instead) */
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid; <0 = that many fewer than fit */
     int stage0_order;          /* raw-rate input: 3 = third-order stage 0, anything else = integrate-and-dump     */
+    int dynamic_preroll;       /* set by the launcher: a unit whose predecessor is still running pre-rolls instead of waiting */
 } nvx_cascade_args;
 
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares

@@ -317,12 +317,14 @@ print(h.hexdigest())
 ''')
     root = str(Path(__file__).resolve().parent.parent)
     digests = []
-    for mode in ("0", "1"):
+    # hand-over with waiting units (round 1's form) / hand-over where a unit whose predecessor is still running pre-rolls
+    # instead (the default; with three streams nearly every unit does) / every unit independent
+    for env in (dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="0"), dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="1"), dict(NVX_INDEPENDENT="1")):
         out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, NVX_INDEPENDENT=mode))
+                             env=dict(os.environ, **env))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(out.stdout.strip().splitlines()[-1])
-    assert digests[0] == digests[1] and len(digests[0]) == 64
+    assert digests[0] == digests[1] == digests[2] and len(digests[0]) == 64
 
 
 def _run_full_size_total(nv, oracle, S, F, ncpu):

@@ -230,9 +230,9 @@ for masks in ([1, 2, 1], [3, 1, 3]):
 print(h.hexdigest())
 ''')
     digests = []
-    for mode in ("0", "1"):
+    for env in (dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="0"), dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="1"), dict(NVX_INDEPENDENT="1")):
         out = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, NVX_INDEPENDENT=mode))
+                             env=dict(os.environ, **env))
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(out.stdout.strip().splitlines()[-1])
-    assert digests[0] == digests[1] and len(digests[0]) == 64
+    assert digests[0] == digests[1] == digests[2] and len(digests[0]) == 64
