@@ -267,6 +267,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
         step()
     pipe.fetch()
     pipe.enable_timing(True); pipe.kernel_time_stats(0, reset=True)
+    pipe.wait_stats(reset=True)
     nv.lib.nvx_channelise_timing(1); nv.channelise_time_stats(reset=True)
     ranks.sync()
     t0 = time.perf_counter()
@@ -278,6 +279,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
     ch_ms, n_c = nv.channelise_time_stats()
+    w_polls, w_units, w_launches = pipe.wait_stats()
     casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
     fused = n_c == 0                                # the fused kernel has no separate channeliser launch
     sub_samples = 8 * W * n_sub
@@ -297,6 +299,8 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                      "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
                      "traffic": None, "flop_per_sample": round(flops_per_sample(2), 2), "samples_per_launch": sub_samples,
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
+                     "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F * (1 if n_c == 0 else 8)), 4),
+                                 "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)},
                      "algorithmic_bytes_per_launch": W * n_raw * 4,
                      "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes; "
                              "only the cascade's fp64 operations are counted, the channeliser's integer work rides on top"},
