@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--stage0", choices=("boxcar", "cic3"), default="boxcar",
                     help="raw-rate front end: integrate-and-dump (default, the headline) or its third-order form "
                          "(nvx_config.stage0_order = 3: 76 dB of alias rejection instead of 25)")
+    ap.add_argument("--no-stage0-extra", action="store_true", help="skip the third-order stage 0 measurement beside the headline (N = 1)")
     ap.add_argument("--variant-a", action="store_true",
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
@@ -510,6 +511,37 @@ def main():
         "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
     }
     pipe.close()
+    # ---- beside the headline (N = 1, default front end only): the same batch through the third-order stage 0, the front
+    # end with real alias rejection -- its own parity sample, ten timed steps, outside the headline's clock
+    if raw and order == 1 and world == 1 and not args.no_stage0_extra:
+        try:
+            p3 = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F,
+                             char_layer=not args.no_charlayer, device=device, stage0_order=3)
+            p3.process_resident(buf, pitch, 0, F); p3.fetch()
+            ids3 = fullsize.spread(S, min(S, 64))
+            checked3, bad3, _ = fullsize.verify_streams(ob, buf, pitch, n_per_stream, 3, lambda s: p3.bits(s, 0), ids3, ncpu)
+            p3.reset()
+            for _ in range(2): p3.process_resident(buf, pitch, 0, F)
+            p3.fetch(); p3.enable_timing(True); p3.kernel_time_stats(0, reset=True)
+            k3 = 10
+            t3 = time.perf_counter()
+            for _ in range(k3): p3.process_resident(buf, pitch, 0, F)
+            p3.fetch()
+            e3 = time.perf_counter() - t3
+            c3, n3 = p3.kernel_time_stats(0)
+            c3 /= max(n3, 1)
+            line["stage0_third_order"] = {
+                "what": "the same batch with nvx_config.stage0_order = 3 (22-tap CIC^3, 76 dB of alias rejection at the NAVTEX "
+                        "offsets where the headline's integrate-and-dump has 25); not part of the timed region above",
+                "steps": k3, "ms_per_step": round(e3 / k3 * 1e3, 3), "value": round(samples_per_step * k3 / e3 / 1e6, 1),
+                "cascade_avg_launch_ms": round(c3, 3), "frac_of_hbm_peak": round(bytes_per_step / (c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if c3 > 0 else None,
+                "parity": not bad3, "parity_streams_checked": checked3}
+            if bad3:
+                print(f"PARITY FAILURE (third-order stage 0): {len(bad3)} of {checked3} streams differ from the CPU oracle, first {bad3[:8]}", file=sys.stderr)
+                parity = False; line["parity"] = False
+            p3.close()
+        except nv.NvxError as e:
+            line["stage0_third_order"] = {"error": str(e)}
     buf.free()
     finish(line, parity, ranks, rank)
 

@@ -7,7 +7,7 @@ mkdir -p $R/gpurun_out; L=$R/gpurun_out/abn.log; : > $L
 for round in 1 2; do for lib in "${libs[@]}"; do
     if [ "$lib" = "-" ]; then unset NAVTEX_AMD_LIB; else export NAVTEX_AMD_LIB=$R/$lib; fi
     echo "== $lib" >> $L
-    timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu --verify 32 "$@" 2>/dev/null >> $L || { echo FAILED >> $L; tail -5 $L; exit 1; }
+    timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu --no-stage0-extra --verify 32 "$@" 2>/dev/null >> $L || { echo FAILED >> $L; tail -5 $L; exit 1; }
 done; done
 python - <<PY
 import json

@@ -5,7 +5,7 @@ V=$1; A=$2; B=$3; shift 3
 mkdir -p $R/gpurun_out; L=$R/gpurun_out/env_ab.log; : > $L
 for val in $A $B $A $B; do
     echo "== $V=$val" >> $L
-    env $V=$val timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu "$@" 2>/dev/null >> $L || { echo FAILED >> $L; tail -5 $L; exit 1; }
+    env $V=$val timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu --no-stage0-extra "$@" 2>/dev/null >> $L || { echo FAILED >> $L; tail -5 $L; exit 1; }
 done
 python - <<PY
 import json

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd $R
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py > $O/trace.log 2>&1; echo "trace rc=$?"
-B="python3 bench.py --no-cpu --steps 4 --warmup 1"
+B="python3 bench.py --no-cpu --no-stage0-extra --steps 4 --warmup 1"
 timeout -k 10 280 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/p1 -- $B > $O/p1.log 2>&1; echo "p1 rc=$?"
 timeout -k 10 280 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/p2 -- $B > $O/p2.log 2>&1; echo "p2 rc=$?"
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/p3 -- $B > $O/p3.log 2>&1; echo "p3 rc=$?"

@@ -5,7 +5,7 @@ L=$R/gpurun_out/streams_curve.log; : > $L
 for S in 64 256 512 1024 2048 2816 4096 8192; do
     F=12; [ $S -gt 4096 ] && F=6
     echo "== streams $S frames $F" >> $L
-    timeout -k 10 300 python bench.py --streams $S --frames $F --steps 8 --warmup 2 --no-cpu --verify 32 2>/dev/null >> $L || { echo FAILED >> $L; }
+    timeout -k 10 300 python bench.py --streams $S --frames $F --steps 8 --warmup 2 --no-cpu --no-stage0-extra --verify 32 2>/dev/null >> $L || { echo FAILED >> $L; }
 done
 python - <<PY
 import json
