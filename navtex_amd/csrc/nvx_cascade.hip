@@ -203,8 +203,8 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // ARGS: how the wave sees the kernel's argument block.  By reference the compiler fetches a field from the kernarg
 // segment where it is used (s_load, per unit) and the pass loop has that many more scalar registers; by value every field
 // sits in a scalar register from the first instruction on.  Same results, different register allocation -- measured on
-// one box, interleaved: raw-rate kernel 20.46 ms by reference against 21.2 by value, 252 kS/s kernel 77.6 against 73.9
-// (DESIGN.md tuning log).  Each kernel gets the form it is faster with.
+// one box, interleaved: raw-rate kernel 20.28 / 20.39 ms by reference against 20.76 / 20.86 by value; the 252 kS/s kernel
+// showed nothing beyond its run-to-run spread, so its code stays as it was (DESIGN.md tuning log).
 template <bool RAW, int NCH, int PFD, bool NT, int S0, typename ARGS>
 __device__ __forceinline__ void cascade_wave_main(ARGS a)
 {
