@@ -180,7 +180,7 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // Work distribution: a persistent grid (as many single-wave workgroups as fit
 // on the chip) pulls units u = part * n_streams + stream from an atomic
 // counter.  A unit is one frame (315 passes, 2.5 MiB raw) of one stream (or a
-// third of one, NVX_UNIT_SPLIT); the FIR histories travel from unit (stream, p)
+// third of one: the last frame of a launch, see the kernel); the FIR histories travel from unit (stream, p)
 // to (stream, p+1) through the per-stream state block in HBM: the producer
 // writes it with agent-scope atomic stores, drains them (vmcnt 0) and then sets
 // done[stream]; the consumer polls done[stream] and reads the block with
@@ -224,11 +224,15 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
     double *xw = (double *)&lds.X[(half & 7) * XS + XH + (lane >> 4)] + comp;
     // 252 kS/s input: the lane holds samples 4*lane .. 4*lane+3 = phases 4*(lane & 1) + s of entry XH + (lane >> 1)
     double2 *xw4 = &lds.X[(lane & 1) * 4 * XS + XH + half];
-    static_assert(NVX_UNIT_SPLIT == 1 || NVX_UNIT_SPLIT == 3, "a unit must end with all pending buffers empty");
     static_assert(S0 == 1 || (S0 == 3 && RAW), "the third-order stage 0 belongs to the raw-rate kernels");
     Stage0Cic3 s0;
     if (S0 == 3) s0.init(lane);
-    const int n_units = a.n_streams * a.n_frames * NVX_UNIT_SPLIT;
+    // Units: whole frames, except that the frames from a.split_from on are handed out in thirds (105 passes; every
+    // pending buffer is empty there too, nvx_kernels.h) -- the launcher asks for that in the launch's LAST frame, so
+    // that the ragged end of the persistent grid is a third of a frame long instead of a whole one.  Positions in a
+    // stream count in thirds (tpart); done[stream] = thirds completed.
+    const int n_full = a.n_streams * a.split_from;
+    const int n_units = n_full + 3 * a.n_streams * (a.n_frames - a.split_from);
 
     for (;;) {
         // ------------------------------------------------------ next unit
@@ -236,8 +240,10 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         if (lane == 0) u = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
-        const int part = u / a.n_streams;              // index of this unit in its stream: frame * NVX_UNIT_SPLIT + third
-        const int stream = u - part * a.n_streams;
+        int tpart, thirds, stream;                     // first third of the unit in its stream, thirds it covers (3 = a frame)
+        if (u < n_full) { const int frame = u / a.n_streams; stream = u - frame * a.n_streams; tpart = 3 * frame; thirds = 3; }
+        else { const int v = u - n_full, q = v / a.n_streams; stream = v - q * a.n_streams; tpart = 3 * a.split_from + q; thirds = 1; }
+        const int part = tpart;                        // (position in the stream, in thirds)
         const unsigned mask = a.chain_masks[stream];
 
         // independent units: rebuild the histories from the nine passes in front of the unit (nvx_kernels.h)
@@ -249,7 +255,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         bool late_publish = false;
         // the input does not depend on the predecessor: request the first pass now (of the unit itself; a unit that turns
         // out to need the pre-roll requests its real first pass again and lets this one go)
-        const u32x4 *unit0 = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + (size_t)part * NVX_UNIT_PASSES * pass_stride + lane;
+        const u32x4 *unit0 = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + (size_t)part * NVX_THIRD_PASSES * pass_stride + lane;
         u32x4 pfA[NPF], pfB[NPF];
         if (!preroll) load_pass<RAW, NT>(pfA, unit0);
 
@@ -286,7 +292,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
             }
         }
         const int pre = preroll ? NVX_PREROLL_PASSES : 0;
-        const int n_pass = pre + NVX_UNIT_PASSES;
+        const int n_pass = pre + thirds * NVX_THIRD_PASSES;
         const u32x4 *src = unit0 - (size_t)pre * pass_stride;
         if (preroll) load_pass<RAW, NT>(pfA, src);
         if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
@@ -300,8 +306,8 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         const double2 *st_in = (part == 0) ? (const double2 *)(a.state_in + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start; the pre-roll starts
         // 576 = 0 mod 9 outputs earlier: same index); FIR3 outputs of the pre-roll are not written
-        cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_UNIT_Y3, a.y3_cap,
-                      ((part % NVX_UNIT_SPLIT) * (NVX_UNIT_PASSES * 64)) % NVX_MIX_N,
+        cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_THIRD_Y3, a.y3_cap,
+                      ((part % 3) * (NVX_THIRD_PASSES * 64)) % NVX_MIX_N,
                       preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
         NVX_WAVE_LDS_FENCE();
         if (!preroll) cw.state_in(st_in); else cw.state_zero();
@@ -371,7 +377,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
             }
             asm volatile("" ::: "memory");
         }
-        if (!a.independent || part == a.n_frames * NVX_UNIT_SPLIT - 1) {
+        if (!a.independent || part + thirds == 3 * a.n_frames) {
             cw.state_out(st);
             if (S0 == 3 && s0.last_pair)
                 __hip_atomic_store((unsigned long long *)(st + NVX_CASCADE_STATE_ENTRIES - 1) + (lane & 1),
@@ -383,7 +389,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        if (lane == 0 && !a.independent) __hip_atomic_store(a.done + stream, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !a.independent) __hip_atomic_store(a.done + stream, part + thirds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -442,14 +448,21 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;
     if (a->max_waves_per_cu < 0 && per_cu + a->max_waves_per_cu >= 4) per_cu += a->max_waves_per_cu;     // "so many fewer than fit"
     const int resident = n_cus * per_cu;
-    const long long units = (long long)a->n_streams * a->n_frames * NVX_UNIT_SPLIT;
+    // The last frame of a launch goes out in thirds when the launch is longer than one round of the grid: the waves that
+    // get no unit in the last round idle for a third of a frame instead of a whole one (4096 x 12: 4.1 % of all wave
+    // time was that idle tail).  NVX_TAIL_SPLIT=0: whole frames only; =n: the last n frames in thirds.
+    nvx_cascade_args args = *a;
+    static const int tail_split = env_int("NVX_TAIL_SPLIT", -1);
+    int split_frames = tail_split >= 0 ? tail_split : ((long long)a->n_streams * a->n_frames > resident ? 1 : 0);
+    if (split_frames > a->n_frames) split_frames = a->n_frames;
+    args.split_from = a->n_frames - split_frames;
+    const long long units = (long long)a->n_streams * (args.split_from + 3LL * split_frames);
     const unsigned grid = (unsigned)(units < resident ? units : resident);
     // Fewer streams than resident waves: the units of one stream would run one after the other and most of the
     // chip would idle.  Then every unit rebuilds its filter histories from the nine passes in front of it
     // (+2.9 % input) and all of them run at once.  NVX_INDEPENDENT=0/1 forces the choice (tests, A/B runs).
-    nvx_cascade_args args = *a;
     static const int force = env_int("NVX_INDEPENDENT", -1);
-    args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames * NVX_UNIT_SPLIT > 1);
+    args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames > 1);
     // hand-over launches: a unit whose predecessor is still running rebuilds its histories instead of waiting for it
     // (NVX_DYNAMIC_PREROLL=0: it waits, as in round 1)
     static const int dynamic = env_int("NVX_DYNAMIC_PREROLL", 1);

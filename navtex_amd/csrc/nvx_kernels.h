@@ -8,16 +8,14 @@
 
 #define NVX_PASSES_PER_FRAME 315          /* 20160 FIR1 outputs per frame / 64 per pass */
 #define NVX_Y3_PER_FRAME 288
-/* A work unit of the cascade is 1/NVX_UNIT_SPLIT of a frame.  A third of a frame (105 passes =
+/* A work unit of the cascade is a frame or a third of one.  A third of a frame (105 passes =
  * 6720 FIR1 outputs = 960 FIR2 outputs = 96 FIR3 outputs) still ends with every pending buffer
  * empty (6720 = 30 * 224 = 60 * 112, 960 = 6 * 160 = 12 * 80); only the mixer index does not
- * return to 0 (6720 mod 9 = 6).  Thirds would shorten the ragged end of the persistent grid, but
- * measured no faster than whole frames (20.58 vs 20.39-20.53 ms, DESIGN.md tuning log): 1 is shipped,
- * -DNVX_UNIT_SPLIT=3 builds the other for A/B runs (parity-tested). */
-#ifndef NVX_UNIT_SPLIT
-#define NVX_UNIT_SPLIT 1
-#endif
-#define NVX_UNIT_PASSES (NVX_PASSES_PER_FRAME / NVX_UNIT_SPLIT)
+ * return to 0 (6720 mod 9 = 6).  Thirds for EVERY frame lose (round 1: 20.58 vs 20.39-20.53 ms; round 2, with the
+ * dynamic pre-roll: 21.0 vs 20.6): a switch of unit costs more than its state traffic.  Thirds for the LAST frame of a
+ * launch shorten the ragged end of the persistent grid from a frame to a third (nvx_cascade.hip, DESIGN.md tuning log). */
+#define NVX_THIRD_PASSES (NVX_PASSES_PER_FRAME / 3)
+#define NVX_THIRD_Y3 (NVX_Y3_PER_FRAME / 3)
 /* Independent units (launches with fewer streams than resident waves): a unit that is not the first of its
  * stream in the launch rebuilds the filter histories from the input instead of waiting for its predecessor.
  * Every value a real output uses must come from real samples in the reference's operation order:
@@ -29,7 +27,6 @@
 #define NVX_PREROLL_PASSES 9
 #define NVX_PREROLL_U 96
 #define NVX_PREROLL_Y2 64
-#define NVX_UNIT_Y3 (NVX_Y3_PER_FRAME / NVX_UNIT_SPLIT)
 #define NVX_CASCADE_CTRL_INTS 4           /* [0] work-queue counter, [1] status (non-zero = spin timeout),  */
                                          /* [2] polls spent waiting for a predecessor, [3] units that waited */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
@@ -60,6 +57,7 @@ typedef struct {
     int max_waves_per_cu;      /* 0 = as many as fit; >0 caps the persistent grid; <0 = that many fewer than fit */
     int stage0_order;          /* raw-rate input: 3 = third-order stage 0, anything else = integrate-and-dump     */
     int dynamic_preroll;       /* set by the launcher: a unit whose predecessor is still running pre-rolls instead of waiting */
+    int split_from;            /* set by the launcher: frames from this one on are handed out in thirds (n_frames = none) */
 } nvx_cascade_args;
 
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares
