@@ -13,10 +13,21 @@ One "step" = one pass of that path over the whole resident batch
 elapsed time and the min-over-ranks of the parity verdict); streams shard one
 subset per GPU, no data-path collective, weak scaling.
 
+`python bench.py --gpus N` works by itself: without a launcher's RANK in the
+environment it starts the N ranks as a child process (torch.distributed.run)
+before touching torch or the GPU, and relays the child's line and exit status.
+Under a launcher (the driver's `python -m torch.distributed.run ... bench.py
+--gpus N`) it is simply one of the ranks.
+
 Every rank checks its OWN shard against the oracle before the timed region (all
 streams at N = 1, a spread sample of them per rank otherwise); the line's
 `parity` is the minimum over ranks, and a failed parity makes the process exit
 with status 3 after printing the line.
+
+At N = 1 the default line also carries, each outside the headline's timed
+region and each with its own parity sample: `stage0_third_order`, `push_path`
+(host-fed streaming through nvx_push_iq, PCIe-inclusive), `variant_a` (the
+252 kS/s cascade kernel) and `wideband` (the fused channeliser + cascade kernel).
 
 Prints ONE JSON line on rank 0.
 """
@@ -71,6 +82,8 @@ def parse():
                     help="raw-rate front end: integrate-and-dump (default, the headline) or its third-order form "
                          "(nvx_config.stage0_order = 3: 76 dB of alias rejection instead of 25)")
     ap.add_argument("--no-stage0-extra", action="store_true", help="skip the third-order stage 0 measurement beside the headline (N = 1)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the side legs of the default line (N = 1): variant_a, wideband, push_path (each a few seconds, outside the timed region)")
     ap.add_argument("--variant-a", action="store_true",
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
@@ -132,6 +145,61 @@ def place_rank(device: int, local_world: int, local_rank: int):
     return {"numa_node": numa, "bound": bound, "cpus": len(have), "ranks_on_numa_node": sharing, "threads": threads}
 
 
+def physical_cores(have) -> tuple:
+    """(physical cores among the CPUs of `have`, hardware threads per core) from the sysfs topology."""
+    seen, smt = set(), 1
+    for c in sorted(have):
+        try:
+            sib = _parse_cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read())
+        except (OSError, ValueError):
+            sib = {c}
+        smt = max(smt, len(sib))
+        seen.add(min(sib))
+    return max(1, len(seen)), smt
+
+
+def cpu_quota():
+    """CPUs the cgroup lets this process use at once (cpu.max), or None when unlimited / unknown."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                return None if f[0] == "max" else round(int(f[0]) / int(f[1]), 2)
+            q = int(f[0])
+            return None if q <= 0 else round(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def self_launch(args, script=None, argv=None) -> None:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD (torch.distributed.run, one process per
+    GPU), relay its one JSON line and its exit status.  Runs before this process has imported torch or made any GPU
+    call: a process that has touched the GPU must never exec, and this one neither touches it nor execs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script or Path(__file__).resolve())] + list(sys.argv[1:] if argv is None else argv)
+    print("bench.py: launching " + " ".join(cmd[2:8]) + " ...", file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr goes straight through
+    lines = proc.stdout.splitlines()
+    js = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)
+    elif proc.returncode == 0:
+        raise SystemExit("bench.py: the ranks printed no JSON line")
+    sys.exit(proc.returncode)
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -169,6 +237,170 @@ def reference_check(ob, raw_stream, order=1):
         return {"error": str(e)[:200]}
 
 
+def cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv):
+    """The oracle (kind "port") on the host cores, on a bounded sample of the bench batch: one thread, this GPU's share of
+    the box (ncpu threads) and every physical core the affinity mask allows -- stands for the reference's per-sample loop
+    receiver/fir1cpp.C:80-136 and what hangs off it.  Each leg is sized to a few seconds of wall time."""
+    have = os.sched_getaffinity(0)
+    n_phys, smt = physical_cores(have)
+    n_all = int(os.environ.get("NVX_CPU_ALL_THREADS", n_phys))
+    n252 = F * nv.FRAME_IN
+    # every thread owns at least one stream; the sample stays under ~4 GB of host memory
+    n_cs = min(max(args.cpu_streams or 2 * ncpu, n_all), S)
+    while n_cs > 2 * ncpu and n_cs * n_per_stream * 4 > (4 << 30):
+        n_cs -= 1
+    sample = np.empty((n_cs, n_per_stream, 2), dtype=np.int16)
+    if pitch == n_per_stream:
+        sample[:] = buf.download(n_cs * n_per_stream * 4, dtype=np.int16).reshape(n_cs, n_per_stream, 2)
+    else:
+        for s in range(n_cs):
+            sample[s] = buf.download(n_per_stream * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+
+    def timed(n_streams, threads, seconds):
+        part = sample[:n_streams]
+        t = ob.bench(part, n_streams, n252, oraw, 1, threads)[0]
+        rep = max(1, int(seconds / max(t, 1e-3)))
+        t = ob.bench(part, n_streams, n252, oraw, 1, threads, repeat=rep)[0]
+        return n_streams * n_per_stream * rep / t / 1e6, rep, t
+
+    n_share = min(n_cs, 2 * ncpu)
+    v_share, rep, secs = timed(n_share, ncpu, 5.0)
+    v_one, _, _ = timed(min(n_cs, 2), 1, 1.5)
+    rate = float(n_per_stream) / (F * 0.32)                  # input samples per second of signal (2.016 M or 252 k)
+    out = {
+        "value": round(v_share, 2), "unit": "Msamples/s", "cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
+        "value_1thread": round(v_one, 2),
+        "sample": f"all {F} frames of the first {n_share} streams of the bench batch ({n_share * n_per_stream / 1e6:.0f} M samples), "
+                  f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
+        "seconds": round(secs, 2),
+        "x_real_time_per_core": round(v_one * 1e6 / rate, 1), "x_real_time": round(v_share * 1e6 / rate, 1),
+    }
+    if n_all > ncpu and n_cs >= n_all:
+        v_all, rep_a, secs_a = timed(n_cs, n_all, 4.0)
+        out.update({"value_all_cores": round(v_all, 2), "cores_all": n_all, "x_real_time_all_cores": round(v_all * 1e6 / rate, 1),
+                    "all_cores_sample": f"all {F} frames of the first {n_cs} streams, processed {rep_a}x in {secs_a:.2f} s, one OpenMP thread per "
+                                        f"physical core of the affinity mask ({len(have)} CPUs, {smt} hardware threads per core)",
+                    "cpu_quota": cpu_quota()})
+    else:
+        out.update({"value_all_cores": None, "cores_all": n_all,
+                    "all_cores_sample": f"not run: {n_all} physical cores in the affinity mask ({len(have)} CPUs, SMT {smt}), share {ncpu}, {n_cs} sample streams"})
+    return out
+
+
+# ----------------------------------------------------------------------------- side legs of the default line (N = 1)
+# Every kernel family and the streaming path get a driver-timed number in the same record as the headline, each with its
+# own parity sample against the oracle, each a few seconds, all OUTSIDE the headline's timed region.
+def leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, char_layer, frames=96, steps=5, n_check=64):
+    """Reference-native rate (SURVEY 8d Variant A): S streams x `frames` frames at 252 kS/s through nvx_fir_cascade<252k,1>
+    (the same bytes per launch as the headline when frames = 96).  fp64-issue-bound: frac is of the 39.3 T no-FMA roof."""
+    n_per = frames * nv.FRAME_IN
+    buf = nv.DeviceBuffer(S * n_per * 4, device=device)
+    try:
+        nv.synth_device([signals.stream_params(nv, s, nv.RATE_IN)[0] for s in range(S)], nv.RATE_IN, n_per, buf, n_per)
+        p = nv.Pipeline(n_streams=S, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=frames, char_layer=char_layer, device=device)
+        p.process_resident(buf, n_per, 0, frames); p.fetch()
+        checked, bad, _ = fullsize.verify_streams(ob, buf, n_per, n_per, False, lambda s: p.bits(s, 0), fullsize.spread(S, min(S, n_check)), ncpu)
+        p.reset()
+        p.process_resident(buf, n_per, 0, frames); p.fetch()
+        p.enable_timing(True); p.kernel_time_stats(0, reset=True); p.wait_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.process_resident(buf, n_per, 0, frames)
+        p.fetch()
+        el = time.perf_counter() - t0
+        c_ms, n_l = p.kernel_time_stats(0); c_ms /= max(n_l, 1)
+        w_polls, w_units, w_launches = p.wait_stats()
+        p.close()
+        tops = flops_per_sample(1) * S * n_per / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
+        return {"what": f"VARIANT A: {S} streams x {frames} frames at 252 kS/s ({S * n_per * 4 / 1e9:.1f} GB), no stage 0, one chain; not part of the timed region above",
+                "kernel": "nvx_fir_cascade<252k,1>", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+                "value": round(S * n_per * steps / el / 1e6, 1), "cascade_avg_launch_ms": round(c_ms, 3),
+                "roofline": {"bound": "fp64_valu", "achieved": round(tops, 2) if tops else None, "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s",
+                             "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(flops_per_sample(1), 2),
+                             "hbm_gbs": round(S * n_per * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None},
+                "handoff_units_waited_frac": round(w_units / max(1, w_launches * S * frames), 4),
+                "parity": not bad, "parity_streams_checked": checked}
+    finally:
+        buf.free()
+
+
+def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_check_wide=8):
+    """Wideband path: W streams at 2.016 MS/s, 16 carriers each, through nvx_wideband_fused."""
+    n_raw, n_sub = F * nv.FRAME_RAW, F * nv.FRAME_IN
+    raw = nv.DeviceBuffer(W * n_raw * 4, device=device)
+    try:
+        nv.synth_device(wideband_streams(nv, signals, 0, W), nv.RATE_RAW, n_raw, raw, n_raw)
+        p = nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=char_layer, device=device)
+        p.process_resident(raw, n_raw, 0, F); p.fetch()
+        nw = min(W, n_check_wide)
+        part = raw.download(nw * n_raw * 4, dtype=np.int16).reshape(nw, n_raw, 2)
+        _secs, cpu_bits = ob.bench_wide(part, nw, n_sub, ncpu, want_bits=True)
+        gpu_bits = [p.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
+        ok = gpu_bits == cpu_bits and all(len(b) > 0 for b in cpu_bits)
+        p.reset()
+        p.process_resident(raw, n_raw, 0, F); p.fetch()
+        p.enable_timing(True); p.kernel_time_stats(0, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            p.process_resident(raw, n_raw, 0, F)
+        p.fetch()
+        el = time.perf_counter() - t0
+        c_ms, n_l = p.kernel_time_stats(0); c_ms /= max(n_l, 1)
+        p.close()
+        sub_samples = 8 * W * n_sub
+        tops = flops_per_sample(2) * sub_samples / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
+        return {"what": f"WIDEBAND: {W} streams x 2.016 MS/s x {F} frames, 16 NAVTEX carriers each (8 sub-bands x 2 chains) = {16 * W} carriers; "
+                        "channeliser + two-chain cascades in one kernel; not part of the timed region above",
+                "kernel": "nvx_wideband_fused" if os.environ.get("NVX_WB_FUSED", "1") != "0" else "nvx_channelise + nvx_fir_cascade<252k,2>",
+                "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "value": round(W * n_raw * steps / el / 1e6, 1),
+                "carrier_equivalent_msamples_per_s": round(16 * W * n_raw * steps / el / 1e6, 1),
+                "kernel_avg_launch_ms": round(c_ms, 3),
+                "roofline": {"bound": "fp64_valu", "achieved": round(tops, 2) if tops else None, "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s",
+                             "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(flops_per_sample(2), 2),
+                             "hbm_gbs": round(W * n_raw * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None,
+                             "note": "only the cascades' fp64 operations are counted; the channeliser's integer work rides on top"},
+                "parity": ok, "parity_carriers_checked": 16 * nw}
+    finally:
+        raw.free()
+
+
+def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_push=4, passes=6):
+    """Streaming runs are reported separately: `n_streams` streams fed from HOST memory through nvx_push_iq ->
+    pinned staging -> hipMemcpyAsync -> kernels -> bits, the loop that replaces receiver/capt_sched.c:484-528.  PCIe-bound by
+    nature (4 B per sample); never `value`."""
+    fpp = min(frames_per_push, F)
+    n_fr = (F // fpp) * fpp
+    n_per = n_fr * nv.FRAME_RAW
+    host = np.empty((n_streams, n_per, 2), dtype=np.int16)
+    for s in range(n_streams):
+        host[s] = buf.download(n_per * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+    chunk = fpp * nv.FRAME_RAW
+    p = nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=fpp, push_mode=True, char_layer=True, device=device)
+
+    def one_pass():
+        for c0 in range(0, n_per, chunk):
+            for s in range(n_streams):
+                p.push(s, host[s, c0:c0 + chunk])
+
+    one_pass(); p.flush()                                   # from reset state: the checked pass (also the warm-up)
+    _secs, want = ob.bench(host, n_streams, n_per // 8, True, 1, ncpu, want_bits=True)
+    got = [p.bits(s, 0) for s in range(n_streams)]
+    ok = got == want and all(len(b) > 0 for b in want)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    p.flush()
+    el = time.perf_counter() - t0
+    p.close()
+    n = passes * n_streams * n_per
+    return {"what": f"HOST-FED: {n_streams} streams x 2.016 MS/s pushed from host memory {fpp} frames at a time (nvx_push_iq -> pinned staging -> "
+                    f"hipMemcpyAsync -> kernels -> bits -> character layer), {passes} passes over {n_fr} frames; PCIe-inclusive, never `value`",
+            "value": round(n / el / 1e6, 1), "unit": "Msamples/s", "h2d_inclusive_gbs": round(4 * n / el / 1e9, 2),
+            "x_real_time": round(n / el / nv.RATE_RAW, 1), "x_real_time_per_stream": round(n / el / nv.RATE_RAW / n_streams, 1),
+            "seconds": round(el, 3), "parity": ok, "parity_streams_checked": n_streams,
+            "parity_note": "bits of the first pass (from reset state) == oracle on every stream; the timed passes repeat the same frames"}
+
+
 def wideband_streams(nv, signals, rank, W, n_phasing=40):
     """W wideband streams: a carrier at k*252 kHz +-14 kHz for k = 0..7, each with its own text."""
     out = []
@@ -200,6 +432,26 @@ class Ranks:
             self.dist.barrier()
             if self.device is not None:
                 self.torch.cuda.synchronize(self.device)
+
+    def gather(self, value: float) -> list:
+        """`value` of every rank, in rank order."""
+        if self.dist is None:
+            return [value]
+        dev = f"cuda:{self.device}" if self.backend == "nccl" else "cpu"
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def describe(self, rank_ms: float, rank_checked: int, rank_casc_ms: float, device: int) -> dict:
+        """What the job looked like from the ranks: the world size the backend actually formed, stragglers, who checked what."""
+        ms = self.gather(rank_ms)
+        return {"world_size_seen": self.dist.get_world_size() if self.dist is not None else 1,
+                "backend": ("rccl" if self.backend == "nccl" else self.backend) if self.dist is not None else "none",
+                "ms_per_step_per_rank": [round(v, 3) for v in ms], "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3),
+                "parity_streams_checked_per_rank": [int(v) for v in self.gather(float(rank_checked))],
+                "cascade_avg_launch_ms_per_rank": [round(v, 3) for v in self.gather(rank_casc_ms)],
+                "device_per_rank": [int(v) for v in self.gather(float(device))]}
 
     def reduce(self, value: float, op: str) -> float:
         if self.dist is None:
@@ -275,6 +527,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     for _ in range(args.steps):
         step()
     pipe.fetch()
+    own_elapsed = time.perf_counter() - t0
     ranks.sync()
     elapsed = ranks.reduce(time.perf_counter() - t0, "max")
     casc_ms, n_l = pipe.kernel_time_stats(0)
@@ -310,6 +563,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
         "form": "fused (one kernel, sub-bands stay in LDS)" if fused else "two kernels (NVX_WB_FUSED=0)",
         "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "demod": {"near_ties": near_ties},
         "host_threads": place["threads"], "placement": place, "gen_seconds": round(t_gen, 1),
+        "ranks": ranks.describe(own_elapsed / args.steps * 1e3, 16 * nw, casc_avg, device),
     }
     pipe.close(); raw.free()
     finish(line, parity, ranks, rank)
@@ -321,9 +575,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if "RANK" not in os.environ and args.gpus > 1:
+        self_launch(args)                        # never returns: relays the child's line and exit status
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     if args.verify == 0:
         raise SystemExit("--verify 0: an unchecked number is no number")
@@ -406,30 +660,11 @@ def main():
     near_all = int(ranks.reduce(float(near), "sum"))
     margin_all = ranks.reduce(margin if evals else 1.0, "min")
 
-    # ---- CPU baseline (rank 0, N = 1 leg of the contract) ---------------------------------------------------------
+    # ---- CPU baseline (rank 0, N = 1 leg of the contract; BASELINE.md 3: one thread AND all physical cores) -------
     cpu = None
     if rank == 0 and not args.no_cpu and world == 1:
-        n_cs = min(args.cpu_streams or 2 * ncpu, S)
-        sample = np.empty((n_cs, n_per_stream, 2), dtype=np.int16)
-        for s in range(n_cs):
-            sample[s] = buf.download(n_per_stream * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
-        n252 = F * nv.FRAME_IN
-        per_pass = n_cs * n_per_stream
-        # calibrate, then size the repeat count for ~6 s wall on all threads
-        sN = ob.bench(sample, n_cs, n252, oraw, 1, ncpu)[0]
-        rep = max(1, int(6.0 / max(sN, 1e-3)))
-        sN = ob.bench(sample, n_cs, n252, oraw, 1, ncpu, repeat=rep)[0]
-        one = min(n_cs, 2)
-        s1 = ob.bench(sample[:one], one, n252, oraw, 1, 1, repeat=max(1, rep // 8))[0]
-        cpu = {
-            "value": round(per_pass * rep / sN / 1e6, 2), "unit": "Msamples/s",
-            "cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
-            "value_1thread": round(one * n_per_stream * max(1, rep // 8) / s1 / 1e6, 2),
-            "sample": f"all {F} frames of the first {n_cs} streams of the bench batch ({per_pass / 1e6:.0f} M raw samples), "
-                      f"processed {rep}x; oracle/nvx_oracle.c (gcc -O2 -ffp-contract=off), OpenMP over streams",
-            "seconds": round(sN, 2),
-        }
-        cpu["reference_check"] = reference_check(ob, sample[0], order) if raw else None
+        cpu = cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv)
+        cpu["reference_check"] = reference_check(ob, buf.download(n_per_stream * 4, dtype=np.int16).reshape(-1, 2), order) if raw else None
     pipe.reset()
 
     # ---- warm-up, then EXACTLY K timed steps ------------------------------------
@@ -447,6 +682,7 @@ def main():
     for _ in range(args.steps):
         step()
     pipe.fetch()                       # all launches done, bits on the host, characters decoded
+    own_elapsed = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier): stragglers show
     ranks.sync()
     elapsed = ranks.reduce(time.perf_counter() - t0, "max")
 
@@ -507,6 +743,7 @@ def main():
                   "span_note": "roofline.demod_span_ms is first-to-last event of the demodulator of launch k, which runs BESIDE the "
                                "cascade of launch k+1 (second stream) and becomes resident as CUs have room: alone it takes ~0.85 ms"},
         "host_threads": place["threads"], "placement": place,
+        "ranks": ranks.describe(own_elapsed / args.steps * 1e3, checked, casc_avg, device),
         "hbm_gbs_whole_job": round(world * bytes_per_step * args.steps / elapsed / 1e9, 1),
         "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
     }
@@ -542,7 +779,27 @@ def main():
             p3.close()
         except nv.NvxError as e:
             line["stage0_third_order"] = {"error": str(e)}
-    buf.free()
+    # ---- side legs (N = 1, default workload only): the streaming path and the other kernel families, driver-timed ----
+    if raw and order == 1 and world == 1 and not args.no_legs:
+        def run_leg(name, fn):
+            nonlocal parity
+            t_leg = time.perf_counter()
+            try:
+                rec = fn()
+            except Exception as e:                       # a leg never takes the headline down with it ...
+                rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+            rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+            line[name] = rec
+            if rec.get("parity") is False:               # ... but wrong bits anywhere fail the run
+                print(f"PARITY FAILURE ({name} leg): GPU bits differ from the CPU oracle", file=sys.stderr)
+                parity = False; line["parity"] = False
+        run_leg("push_path", lambda: leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=min(64, S)))
+        buf.free()                                       # room for the 252 kS/s batch of the same size
+        run_leg("variant_a", lambda: leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, not args.no_charlayer,
+                                                   frames=8 * F if S * 8 * F * nv.FRAME_IN * 4 <= (140 << 30) else F))
+        run_leg("wideband", lambda: leg_wideband(nv, ob, signals, max(1, S // 8), F, device, ncpu, not args.no_charlayer))
+    else:
+        buf.free()
     finish(line, parity, ranks, rank)
 
 

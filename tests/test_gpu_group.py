@@ -120,3 +120,40 @@ def test_member_threads_bind_to_the_device_numa_node(nv):
     assert out["n"] >= 0 and out["after"] <= before
     assert out["n"] in (0, len(out["after"]))
     assert os.sched_getaffinity(0) == before                   # the calling thread of the test is untouched
+
+
+def test_group_two_physical_devices(nv):
+    """Members on devices 0 and 1 == one handle of all the streams on device 0: the per-device launch cache
+    (nvx_cascade.hip), the per-member hipSetDevice discipline and the members' NUMA binding where they matter.
+    Skipped on a one-GPU box; any multi-GPU box the suite lands on runs it."""
+    if nv.device_count() < 2:
+        pytest.skip("needs two physical devices")
+    S, F = 26, 14
+    masks = [(1, 2, 3)[s % 3] for s in range(S)]
+    labels = [[1000 + s, 2000 + s] for s in range(S)]
+    buf, pitch, streams = _batch(nv, S, F, masks)
+    plan = [5, 5, 4]
+    with nv.Pipeline(n_streams=S, raw_rate=False, chain_masks=masks, labels=labels, max_frames=5) as one:
+        f0 = 0
+        for k in plan:
+            one.process_resident(buf, pitch, f0, k); f0 += k
+        one.fetch()
+        want_bits = {(s, c): one.bits(s, c) for s in range(S) for c in range(2)}
+        want_msgs = list(one.messages)
+    with nv.Group([0, 1], n_streams=S, raw_rate=False, chain_masks=masks, labels=labels, max_frames=5) as g:
+        assert g.members == [(0, 0, 13), (1, 13, 13)]
+        # member 1's shard lives on ITS device, generated there from the same descriptors
+        b1 = nv.DeviceBuffer(13 * pitch * 4, device=1)
+        nv.synth_device(streams[13:], nv.RATE_IN, pitch, b1, pitch)
+        ptrs = [buf.ptr, b1.ptr]
+        for rep in range(2):
+            f0 = 0
+            for k in plan:
+                g.process_resident(ptrs, pitch, f0, k); f0 += k
+            g.fetch()
+            got = {(s, c): g.bits(s, c) for s in range(S) for c in range(2)}
+            assert got == want_bits, f"round {rep}: bits differ between two devices and one"
+            assert g.messages == want_msgs, f"round {rep}: messages (or their order) differ"
+            g.reset()
+        b1.free()
+    buf.free()

@@ -148,7 +148,69 @@ def test_two_ranks_on_one_gpu_run_the_hip_path_and_check_their_own_shards(tmp_pa
     assert rec["config"]["streams_per_gpu"] == 96 and rec["scaling"] == "weak"
 
 
-def test_bench_refuses_multi_gpu_without_launcher():
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+SELF_LAUNCH_WORKER = textwrap.dedent("""
+    import json, os, sys
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    print("chatter from rank", rank)                     # must not reach the parent's stdout
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "argv": sys.argv[1:], "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    sys.exit(int(os.environ.get("NVX_TEST_EXIT", "0")))
+""")
+
+
+@pytest.mark.parametrize("status", [0, 3])
+def test_bench_launches_its_own_ranks_and_relays_line_and_status(tmp_path, status):
+    """`python bench.py --gpus N` with no launcher around it: bench.self_launch starts the ranks as a child
+    (torch.distributed.run), hands its own arguments on, relays exactly the child's JSON line on stdout and the child's
+    failure as a non-zero exit status.  (The ranks here are a stand-in script: no GPU in this container.)"""
+    import json
+    worker = tmp_path / "worker.py"
+    worker.write_text(SELF_LAUNCH_WORKER)
+    driver = tmp_path / "driver.py"
+    driver.write_text(textwrap.dedent(f"""
+        import sys, argparse
+        sys.path.insert(0, {str(ROOT)!r})
+        import bench
+        bench.self_launch(argparse.Namespace(gpus=2), script={str(worker)!r}, argv=["--gpus", "2", "--steps", "7"])
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["NVX_TEST_EXIT"] = str(status)
+    out = subprocess.run([sys.executable, str(driver)], capture_output=True, text=True, timeout=600, env=env)
+    assert (out.returncode == 0) == (status == 0), out.stderr[-2000:]
+    assert len(out.stdout.splitlines()) == 1, out.stdout
+    rec = json.loads(out.stdout)
+    assert rec == {"n_gpus": 2, "argv": ["--gpus", "2", "--steps", "7"], "master": "127.0.0.1"}
+    assert "chatter from rank" in out.stderr
+
+
+def test_bench_multi_gpu_without_launcher_reaches_the_ranks():
+    """The real bench.py, `--gpus 2`, no launcher: it no longer refuses -- it starts two ranks, and what stops them HERE is
+    only that this container has no GPU (the product has no CPU path); the failure comes back as the exit status."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--streams", "8", "--frames", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
-    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+    if out.returncode == 0:                              # on a GPU box with two devices the run simply succeeds
+        import json
+        assert json.loads(out.stdout.splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert "launching" in out.stderr and "--nproc-per-node=2" in out.stderr
+        assert "torch.distributed.run (one process per GPU)" not in out.stderr
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_runs_two_ranks_on_one_gpu():
+    """the command the driver uses for N = 1 works unchanged for N = 2 -- `python bench.py --gpus 2` with no
+    launcher around it (gloo for the scalars and device 0 for both ranks: RCCL refuses two ranks on one device)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(NVX_BENCH_BACKEND="gloo", NVX_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--streams", "96", "--frames", "6", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(out.stdout.splitlines()) == 1
+    rec = json.loads(out.stdout)
+    assert rec["n_gpus"] == 2 and rec["parity"] is True and rec["parity_streams_checked"] == 64
+    r = rec["ranks"]
+    assert r["world_size_seen"] == 2 and r["backend"] == "gloo" and r["parity_streams_checked_per_rank"] == [32, 32]
+    assert len(r["ms_per_step_per_rank"]) == 2 and r["ms_per_step_min"] <= r["ms_per_step_max"] <= rec["ms_per_step"] * 1.5
+    assert r["device_per_rank"] == [0, 0]
