@@ -243,7 +243,12 @@ def cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv):
     receiver/fir1cpp.C:80-136 and what hangs off it.  Each leg is sized to a few seconds of wall time."""
     have = os.sched_getaffinity(0)
     n_phys, smt = physical_cores(have)
-    n_all = int(os.environ.get("NVX_CPU_ALL_THREADS", n_phys))
+    # "all cores" = the physical cores this process may really use at once: the affinity mask, cut down to the cgroup's
+    # CPU quota when there is one (the pool's one-GPU boxes: 256 CPUs in the mask, a quota of 16 -- 128 threads there
+    # only measure the throttle: 10.8 G samples/s against 19.4 G on 16, profiles/r03/a0_*)
+    quota = cpu_quota()
+    n_all = n_phys if quota is None else max(1, min(n_phys, int(quota)))
+    n_all = int(os.environ.get("NVX_CPU_ALL_THREADS", n_all))
     n252 = F * nv.FRAME_IN
     # every thread owns at least one stream; the sample stays under ~4 GB of host memory
     n_cs = min(max(args.cpu_streams or 2 * ncpu, n_all), S)
@@ -275,15 +280,18 @@ def cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv):
         "seconds": round(secs, 2),
         "x_real_time_per_core": round(v_one * 1e6 / rate, 1), "x_real_time": round(v_share * 1e6 / rate, 1),
     }
+    where = f"{n_phys} physical cores in the affinity mask ({len(have)} CPUs, {smt} hardware threads per core), cgroup CPU quota {quota if quota is not None else 'none'}"
     if n_all > ncpu and n_cs >= n_all:
         v_all, rep_a, secs_a = timed(n_cs, n_all, 4.0)
         out.update({"value_all_cores": round(v_all, 2), "cores_all": n_all, "x_real_time_all_cores": round(v_all * 1e6 / rate, 1),
-                    "all_cores_sample": f"all {F} frames of the first {n_cs} streams, processed {rep_a}x in {secs_a:.2f} s, one OpenMP thread per "
-                                        f"physical core of the affinity mask ({len(have)} CPUs, {smt} hardware threads per core)",
-                    "cpu_quota": cpu_quota()})
+                    "all_cores_sample": f"all {F} frames of the first {n_cs} streams, processed {rep_a}x in {secs_a:.2f} s, one OpenMP thread per usable physical core: {where}"})
     else:
-        out.update({"value_all_cores": None, "cores_all": n_all,
-                    "all_cores_sample": f"not run: {n_all} physical cores in the affinity mask ({len(have)} CPUs, SMT {smt}), share {ncpu}, {n_cs} sample streams"})
+        # the share IS everything this process may use (or the sample cannot give every thread a stream): same measurement
+        out.update({"value_all_cores": round(v_share, 2) if n_all <= ncpu else None, "cores_all": min(n_all, ncpu) if n_all <= ncpu else n_all,
+                    "x_real_time_all_cores": round(v_share * 1e6 / rate, 1) if n_all <= ncpu else None,
+                    "all_cores_sample": (f"= the {ncpu}-thread measurement above: {where}" if n_all <= ncpu else
+                                         f"not run: {n_cs} sample streams for {n_all} threads; {where}")})
+    out.update({"physical_cores_in_mask": n_phys, "smt": smt, "cpu_quota": quota})
     return out
 
 
