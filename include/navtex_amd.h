@@ -71,7 +71,13 @@ NVX_API void init_fir2_wrapper(void);                      /* receiver/nav_sched
 int add_message(char *bbbb, char *message, int freq);
 
 /* Drains whatever the push surface has buffered so far in whole frames and
- * waits for the GPU (the reference has no equivalent: it never terminates). */
+ * waits for the GPU (the reference has no equivalent: it never terminates).
+ * Results of launched frames reach add_message without it: with the next
+ * launch, or within ~50 ms through the singleton's housekeeping thread
+ * (nvx_poll).  What only this call delivers is the tail of a capture that
+ * STOPS: samples sit in the singleton's 4096-sample buffer and in frames not
+ * yet complete (up to 0.32 s of signal); a program that ends a capture calls
+ * it once, an endless receiver (capt_sched.c:618-621) never needs to.       */
 NVX_API int nvx_shim_flush(void);
 /* Bits the singleton has produced so far for chain 0 (518) / 1 (490).        */
 NVX_API size_t nvx_shim_bits(int chain, char *out, size_t cap);
@@ -115,10 +121,19 @@ NVX_API int  nvx_capture_stop(nvx_capture *c);
 /* complex samples offered by the producer / dropped on overrun / handed to the GPU pipeline */
 NVX_API void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed);
 /* Health of the consumer while it runs: returns the error that stopped it (NVX_OK while it is alive; a HIP failure is
- * the only thing that stops it early) and, optionally, how often it found the handle's staging full because ANOTHER
- * stream of the same handle had stalled -- that is back-pressure: the consumer keeps the samples in the ring, retries
- * every 50 ms, and the ring's overrun accounting (dropped) counts what is lost meanwhile.                           */
+ * the only thing that stops it early) and, optionally, how often it met back-pressure (NVX_ERR_FULL from the handle).
+ * Since round 3 the streams of a handle advance independently (section C, "stream independence"), so another stream's
+ * stall no longer produces back-pressure; only a wideband handle in its two-kernel A/B form (NVX_WB_FUSED=0) still
+ * launches all streams together and can report it.                                                                 */
 NVX_API int  nvx_capture_error(nvx_capture *c, uint64_t *full_waits);
+/* Silent-radio detection.  The reference has one radio and only prints sdrplay_api_DeviceRemoved when it disappears
+ * (receiver/capt_sched.c:210-212).  With several radios on one handle a silent one must not hold the others: when the
+ * consumer has handed on no sample for the stall timeout (default 2 s; <= 0 disables), it marks its stream INACTIVE
+ * (nvx_stream_set_active) -- launches stop waiting for it -- and counts the event.  nvx_capture_stalled returns 1
+ * while the stream is marked silent, 0 otherwise (negative: error); the first sample that arrives afterwards makes
+ * the stream active again and it continues bit-exactly from its own carried state.                                */
+NVX_API int  nvx_capture_stalled(nvx_capture *c, uint64_t *stall_events);
+NVX_API void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds);
 /* debug recording (the reference's debug_mode, capt_sched.c:87-101 PrepWav/EndWav and :516):
  * every span the consumer hands to the pipeline is also appended to a 2-channel 16-bit WAV
  * at the handle's input rate.  filename NULL stops and closes; nvx_capture_stop closes too. */
@@ -175,12 +190,30 @@ NVX_API int  nvx_reset(nvx_handle *h);
 /* ---- host-input path (pinned staging + hipMemcpyAsync) -------------------
  * Interleaved I,Q int16 (the layout of the reference's sample_buffer,
  * capt_sched.c:120-129) or planar xi/xq (the callback's layout).  Samples are
- * at the handle's input rate.  A launch happens whenever every stream has a
- * whole frame staged.  Returns NVX_OK or NVX_ERR_FULL.                       */
+ * at the handle's input rate.
+ * Stream independence: the chains share no state (receiver/decoder.h:31-60,
+ * receiver/nav_b_sm.h:92-114), so the streams of a handle need no common
+ * clock.  A launch goes out when every ACTIVE stream has a whole frame staged
+ * and covers all of them; when one stream's staging is full (max_frames + 1
+ * frames) before that, the launch goes out with the streams that HAVE a frame,
+ * each carrying its own filter / demodulator state -- a stalled or slower
+ * radio never blocks the others, and rejoins later bit-exactly.  Returns
+ * NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel form). */
 NVX_API int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq_interleaved, size_t n);
 NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n);
+/* Mark a stream of a push-mode handle inactive (0): launches no longer wait for it (a silent radio).  Pushing to it
+ * makes it active again.  nvx_stream_stats: the flag, the frames the stream has been through since create / reset,
+ * and how many launches of the handle covered only some of its streams (any out pointer may be NULL).           */
+NVX_API int nvx_stream_set_active(nvx_handle *h, int stream, int active);
+NVX_API int nvx_stream_stats(nvx_handle *h, int stream, int *active, uint64_t *frames_done, uint64_t *partial_launches);
 /* wait for all launched work, deliver bits/messages                          */
 NVX_API int nvx_flush(nvx_handle *h);
+/* Take in whatever launched work has ALREADY finished -- bits appended, character layer run, messages delivered on
+ * the calling thread -- and return at once; never waits for the GPU.  Results otherwise reach the host with the next
+ * launch, flush or fetch; a caller with a loop of its own (the capture ring's consumer does this every 50 ms, the
+ * singleton of section A on a housekeeping thread) calls this so that the last message before a quiet spell is not
+ * held back until signal arrives again.                                                                           */
+NVX_API int nvx_poll(nvx_handle *h);
 /* copy out and consume decoded bits ('B'/'Y') of one chain; returns count.
  * The receiver runs unattended for weeks (main(), receiver/capt_sched.c:558, and its
  * endless capture loop :618-621), so the library keeps

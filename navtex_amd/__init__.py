@@ -189,6 +189,20 @@ class Pipeline:
     def flush(self) -> None:
         N.check(lib.nvx_flush(self._h), "nvx_flush")
 
+    def poll(self) -> None:
+        """Take in whatever launched work has already finished; never waits (nvx_poll)."""
+        N.check(lib.nvx_poll(self._h), "nvx_poll")
+
+    def set_active(self, stream: int, active: bool) -> None:
+        """A silent stream (active=False) is one the launches of a push-mode handle no longer wait for."""
+        N.check(lib.nvx_stream_set_active(self._h, stream, int(active)), "nvx_stream_set_active")
+
+    def stream_stats(self, stream: int = 0) -> Tuple[bool, int, int]:
+        """(active, frames the stream has been through, launches of the handle that covered only some streams)."""
+        a, f, p = C.c_int(), C.c_uint64(), C.c_uint64()
+        N.check(lib.nvx_stream_stats(self._h, stream, C.byref(a), C.byref(f), C.byref(p)), "nvx_stream_stats")
+        return bool(a.value), f.value, p.value
+
     def decode_wav(self, path: str, stream: int = 0) -> int:
         return N.check(lib.nvx_decode_wav(self._h, stream, path.encode()), "nvx_decode_wav")
 

@@ -79,6 +79,9 @@ def _load() -> C.CDLL:
         "nvx_bind_thread_to_device": (i, [i]),
         "nvx_demod_tie_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
         "nvx_capture_error": (i, [vp, C.POINTER(C.c_uint64)]),
+        "nvx_capture_stalled": (i, [vp, C.POINTER(C.c_uint64)]), "nvx_capture_set_stall_timeout": (None, [vp, C.c_double]),
+        "nvx_stream_set_active": (i, [vp, i, i]), "nvx_poll": (i, [vp]),
+        "nvx_stream_stats": (i, [vp, i, C.POINTER(i), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "nvx_kernel_time_stats": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_uint64), i]),
         "nvx_debug_y3": (sz, [vp, i, i, vp, sz]), "nvx_debug_dphi": (sz, [vp, i, i, vp, sz]),
         "nvx_device_count": (i, []), "nvx_device_alloc": (vp, [i, sz]), "nvx_device_free": (None, [i, vp]),
@@ -108,7 +111,11 @@ def _load() -> C.CDLL:
         "nvx_store_stats": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if os.environ.get("NAVTEX_AMD_LIB"):         # an older build in an A/B run may lack the newest entry points
+                continue
+            raise ImportError(f"{_LIB_PATH} does not export {name}: rebuild it (python navtex_amd/build.py)")
         fn.restype, fn.argtypes = res, args
     return lib
 

@@ -83,12 +83,13 @@ static void free_handle(nvx_handle *h)
         hipFree(r.d_bits); hipFree(r.d_nbits);
         if (r.h_bits) hipHostFree(r.h_bits);
         if (r.h_nbits) hipHostFree(r.h_nbits);
+        hipFree(r.d_part); if (r.h_part) hipHostFree(r.h_part);
+        if (r.copied) hipEventDestroy(r.copied);
         if (r.done) hipEventDestroy(r.done);
         for (int i = 0; i < 6; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
     }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
-        if (h->stage_free[i]) hipEventDestroy(h->stage_free[i]);
     }
     for (auto &s : h->slots) {
         if (s.sitor) nvx_sitor_free(s.sitor);
@@ -124,6 +125,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     h->bits_cap = (((h->y3_cap / 8 + 8) + 31) / 32) * 4;
     h->masks.resize(h->n_streams);
     h->slots.resize(h->n_slots);
+    h->parity.assign(h->n_in, 0);
+    h->g0s.assign(h->n_in, 0);
     bool any_two = false;
     for (int s = 0; s < h->n_streams; s++) {
         uint8_t m = cfg->chain_masks ? cfg->chain_masks[s] : (uint8_t)cfg->chain_mask;
@@ -179,6 +182,9 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
         CR_TRY(hipHostMalloc((void **)&r.h_bits, (size_t)h->n_slots * h->bits_cap, hipHostMallocDefault));
         CR_TRY(hipHostMalloc((void **)&r.h_nbits, (size_t)h->n_slots * sizeof(int), hipHostMallocDefault));
+        CR_TRY(hipMalloc(&r.d_part, (size_t)h->n_in * sizeof(nvx_part)));
+        CR_TRY(hipHostMalloc((void **)&r.h_part, (size_t)h->n_in * sizeof(nvx_part), hipHostMallocDefault));
+        CR_TRY(hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         for (int i = 0; i < 6; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
@@ -196,10 +202,12 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
         for (int i = 0; i < 2; i++) {
             CR_TRY(hipHostMalloc((void **)&h->h_stage[i], (size_t)h->n_in * h->stage_cap * 4, hipHostMallocDefault));
-            CR_TRY(hipEventCreateWithFlags(&h->stage_free[i], hipEventDisableTiming));
+            h->set_launch[i].assign(h->n_in, 0);
         }
         CR_TRY(hipMalloc(&h->d_in, (size_t)h->n_in * cfg->max_frames * h->frame_in * 4));
         h->fill.assign(h->n_in, 0);
+        h->cur.assign(h->n_in, 0);
+        h->active.assign(h->n_in, 1);
     }
 #undef CR_TRY
     rc = nvx_reset(h);
@@ -220,7 +228,9 @@ extern "C" int nvx_reset(nvx_handle *h)
     h->launch_done_valid = false;
     for (auto &r : h->res) r.pending = false;
     h->collected = h->launched;
-    h->g0 = 0;
+    std::fill(h->parity.begin(), h->parity.end(), (uint8_t)0);
+    std::fill(h->g0s.begin(), h->g0s.end(), 0ull);
+    h->diverged = false;
     h->demod_pending[0] = h->demod_pending[1] = false;
     h->fsm_pending = false;
     if (h->stream3) {
@@ -243,7 +253,12 @@ extern "C" int nvx_reset(nvx_handle *h)
     HIP_TRY(hipMemcpyAsync(h->d_ties, &ties0, sizeof ties0, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (auto &s : h->slots) { s.bits.clear(); s.base = 0; s.polled = 0; if (s.sitor) nvx_sitor_reset(s.sitor); }
-    if (!h->fill.empty()) std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
+    if (!h->fill.empty()) {
+        std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
+        std::fill(h->active.begin(), h->active.end(), (uint8_t)1);
+        // (every copy out of the staging sets has finished: the streams were synchronised above)
+        for (int i = 0; i < 2; i++) std::fill(h->set_launch[i].begin(), h->set_launch[i].end(), (uint64_t)0);
+    }
     return NVX_OK;
 }
 
@@ -255,10 +270,13 @@ bool nvx_wb_fused()
 
 // launch cascade + demod over n_frames frames of [n_streams][pitch] packed IQ
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
-                      bool input_on_stream3)
+                      bool input_on_stream3, const int *part, int n_part)
 {
     if (n_frames < 1 || n_frames > h->cfg.max_frames) { nvx_set_error("n_frames %d outside 1..max_frames %d", n_frames, h->cfg.max_frames); return NVX_ERR_ARG; }
     if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
+    if (part && (n_part < 1 || n_part > h->n_in)) { nvx_set_error("launch with %d of %d streams", n_part, h->n_in); return NVX_ERR_ARG; }
+    if (part && n_part == h->n_in) part = nullptr;      // ascending and distinct: that is every stream
+    if (part && h->cfg.wideband && !nvx_wb_fused()) { nvx_set_error("the two-kernel wideband form (NVX_WB_FUSED=0) launches all streams together"); return NVX_ERR_STATE; }
     Result &r = h->res[h->launched % RESULT_SLOTS];
     // Ring full: take in the OLDEST result only (launched RESULT_SLOTS launches ago, long finished), so that the launches
     // behind it keep the GPU busy while the host appends its bits.  (Collecting everything here drained the pipeline every
@@ -266,16 +284,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (r.pending) { int rc = nvx_collect_locked(h, h->launched - RESULT_SLOTS + 1); if (rc != NVX_OK) return rc; }
     // ... and whatever else has finished meanwhile (no waiting): its bits and messages reach the user now, behind the
     // launches that are still queued on the GPU, instead of with the next fetch
-    while (h->collected < h->launched) {
-        Result &o = h->res[h->collected % RESULT_SLOTS];
-        if (o.pending) {
-            const hipError_t q = hipEventQuery(o.done);
-            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
-            if (q != hipSuccess) { nvx_set_error("hipEventQuery: %s", hipGetErrorString(q)); return NVX_ERR_HIP; }
-        }
-        int rc = nvx_collect_locked(h, h->collected + 1);
-        if (rc != NVX_OK) return rc;
-    }
+    { int rc = nvx_collect_ready_locked(h); if (rc != NVX_OK) return rc; }
 
     // a launch on another stream than its predecessor: order it behind the predecessor's last operation
     if (h->launch_done_valid && st != h->last_launch_stream) HIP_TRY(hipStreamWaitEvent(st, h->launch_done, 0));
@@ -326,10 +335,30 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     static const int demod_overlap = getenv("NVX_DEMOD_OVERLAP") ? atoi(getenv("NVX_DEMOD_OVERLAP")) : 1;
     hipStream_t s2 = (fsm_overlap || demod_overlap > 0) ? h->stream2 : st;
     hipStream_t sd = demod_overlap > 0 ? h->stream2 : st;
+    // Who takes part.  While every launch has covered every stream, all streams share one state-block parity and one
+    // sample count and the kernels need no list.  From the first partial launch on (a stream of a push-mode handle had
+    // no frame) the streams are on their own clocks: the launch carries a list with each participant's parity and g0.
+    const int per_part = h->cfg.wideband ? NVX_WB_SUBBANDS : 1;          // decoded streams per input stream
+    if (part) { h->diverged = true; h->partial_launches++; }
+    r.n_part = 0;
+    const nvx_part *d_list = nullptr;
+    if (h->diverged) {
+        r.n_part = part ? n_part : h->n_in;
+        for (int i = 0; i < r.n_part; i++) {
+            const int s = part ? part[i] : i;
+            if (s < 0 || s >= h->n_in || (part && i > 0 && part[i] <= part[i - 1])) { nvx_set_error("launch list: stream %d out of order or range", s); return NVX_ERR_ARG; }
+            r.h_part[i] = nvx_part{ s, (int)h->parity[s], h->g0s[s] };
+        }
+        // (the slot's previous launch has been collected above, so neither copy of its list is still in use)
+        HIP_TRY(hipMemcpyAsync(r.d_part, r.h_part, (size_t)r.n_part * sizeof(nvx_part), hipMemcpyHostToDevice, st));
+        d_list = r.d_part;
+    }
+    const int n_here = h->diverged ? r.n_part : h->n_in;                 // input streams in this launch
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
-    ca.n_frames = n_frames; ca.n_streams = h->n_streams; ca.chain_masks = h->d_masks;
-    ca.state_in = h->d_cstate[h->launched & 1]; ca.state_out = h->d_cstate[(h->launched + 1) & 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    ca.n_frames = n_frames; ca.n_streams = h->cfg.wideband ? h->n_streams : n_here; ca.chain_masks = h->d_masks;
+    ca.part = h->cfg.wideband ? nullptr : d_list; ca.parity = (int)h->parity[0];
+    ca.state[0] = h->d_cstate[0]; ca.state[1] = h->d_cstate[1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
     ca.stage0_order = h->cfg.stage0_order;
@@ -337,7 +366,8 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
-    da.g0 = h->g0; da.dstate = h->d_dd; da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
+    da.g0 = h->g0s[0]; da.part = d_list; da.n_part = r.n_part; da.per_part = per_part;
+    da.dstate = h->d_dd; da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi; da.ties = h->d_ties;
 
     // cascade on `st`: it may not overwrite y3[yb] before the demodulator of two launches ago has read it
@@ -347,9 +377,10 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (fused) {
         nvx_wideband_args wa{};
         wa.raw = (const uint32_t *)d_wide; wa.pitch = wide_pitch; wa.first_sample = wide_first;
-        wa.n_wide = h->n_in; wa.n_frames = n_frames; wa.chain_masks = h->d_masks;
-        wa.state_in = ca.state_in; wa.state_out = ca.state_out;
-        wa.hist_in = h->d_whist[wb]; wa.hist_out = h->d_whist[wb ^ 1];       // launch k reads [k & 1], writes the other
+        wa.n_wide = n_here; wa.n_frames = n_frames; wa.chain_masks = h->d_masks;
+        wa.part = d_list; wa.parity = (int)h->parity[0];
+        wa.state[0] = h->d_cstate[0]; wa.state[1] = h->d_cstate[1];
+        wa.hist[0] = h->d_whist[0]; wa.hist[1] = h->d_whist[1];             // a stream reads [its parity], writes the other
         wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
         wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done;
         HIP_TRY(nvx_launch_wideband_fused(&wa, st));
@@ -385,8 +416,36 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     r.pending = true;
     h->launched++;
     h->last_n3 = da.n3;
-    h->g0 += (unsigned long long)da.n3;
+    for (int i = 0; i < n_here; i++) {                   // the participants have moved on: other block, n3 more samples
+        const int s = h->diverged ? r.h_part[i].stream : i;
+        h->parity[s] ^= 1; h->g0s[s] += (unsigned long long)da.n3;
+    }
     return NVX_OK;
+}
+
+// take in every launched block that has already finished (hipEventQuery, never waits), oldest first
+int nvx_collect_ready_locked(nvx_handle *h)
+{
+    while (h->collected < h->launched) {
+        Result &o = h->res[h->collected % RESULT_SLOTS];
+        if (o.pending) {
+            const hipError_t q = hipEventQuery(o.done);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (q != hipSuccess) { nvx_set_error("hipEventQuery: %s", hipGetErrorString(q)); return NVX_ERR_HIP; }
+        }
+        int rc = nvx_collect_locked(h, h->collected + 1);
+        if (rc != NVX_OK) return rc;
+    }
+    return NVX_OK;
+}
+
+extern "C" int nvx_poll(nvx_handle *h)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->collected == h->launched) return NVX_OK;          // nothing in flight: no HIP call at all
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return nvx_collect_ready_locked(h);
 }
 
 // wait for the launched blocks in front of `upto` (default: all of them), append bits, run the character layer
@@ -412,16 +471,21 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
                 h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
             }
             std::atomic<int> bad_slot{ -1 };
+            // the chains of this launch: every slot, or (a launch with a participant list) the 2 * per_part slots of each
+            // participating input stream -- the other slots' rows of this result hold nothing from this launch
+            const int per_slots = 2 * (h->cfg.wideband ? NVX_WB_SUBBANDS : 1);
+            const int n_chains = r.n_part ? r.n_part * per_slots : h->n_slots;
             auto work = [&](int lo, int hi) {
-                for (int i = lo; i < hi; i++) {
+                for (int k = lo; k < hi; k++) {
+                    const int i = r.n_part ? r.h_part[k / per_slots].stream * per_slots + k % per_slots : k;
                     Slot &s = h->slots[i];
                     if (!s.active) continue;
                     int n = r.h_nbits[i];
-                    if (n > h->bits_cap * 8) { bad_slot = i; continue; }
+                    if (n < 0 || n > h->bits_cap * 8) { bad_slot = i; continue; }
                     const uint32_t *pw = (const uint32_t *)(r.h_bits + (size_t)i * h->bits_cap);
                     const size_t at = s.bits.size();
                     s.bits.resize(at + (size_t)n);
-                    for (int k = 0; k < n; k++) s.bits[at + k] = ((pw[k >> 5] >> (k & 31)) & 1u) ? 'B' : 'Y';
+                    for (int b = 0; b < n; b++) s.bits[at + b] = ((pw[b >> 5] >> (b & 31)) & 1u) ? 'B' : 'Y';
                     if (s.sitor) nvx_sitor_receive_bits(s.sitor, s.bits.data() + at, (size_t)n);
                     if (s.bits.size() > 2 * h->bit_history) {                // a receiver runs for weeks: bound the poll history
                         const size_t drop = s.bits.size() - h->bit_history;
@@ -438,14 +502,12 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
                 return n < 1 ? 1 : (n > 16 ? 16 : n);
             }();
             const int host_threads = h->cfg.host_threads > 0 ? std::min(h->cfg.host_threads, 16) : env_threads;
-            const int nt = (h->n_slots >= 256 && h->cfg.char_layer) ? host_threads : 1;
+            const int nt = (n_chains >= 256 && h->cfg.char_layer) ? host_threads : 1;
             if (nt > 1) {
-                std::vector<std::thread> pool;
-                const int per = (h->n_slots + nt - 1) / nt;
-                for (int t = 0; t < nt; t++) pool.emplace_back(work, t * per, std::min(h->n_slots, (t + 1) * per));
-                for (auto &t : pool) t.join();
+                const int per = (n_chains + nt - 1) / nt;
+                h->pool.run(nt, [&](int t) { work(std::min(n_chains, t * per), std::min(n_chains, (t + 1) * per)); });
             } else {
-                work(0, h->n_slots);
+                work(0, n_chains);
             }
             if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot.load()); return NVX_ERR_STATE; }
             for (int i = 0; i < h->n_slots; i++) if (!h->slots[i].outbox.empty()) deliver_outbox(h, i / 2, h->slots[i]);

@@ -16,18 +16,35 @@ struct nvx_capture {
     std::atomic<bool> stop{ false }, paused{ false };
     std::atomic<int> error{ NVX_OK };
     int stalled = 0;                            // consumer only: consecutive back-pressure rounds in which nothing was taken
+    // A radio that goes silent (unplugged: receiver/capt_sched.c:210-212 only prints sdrplay_api_DeviceRemoved) must not
+    // hold the other streams of the handle: after stall_ms without a sample handed on, the consumer marks its stream
+    // inactive (nvx_stream_set_active) -- launches stop waiting for it -- and says so (nvx_capture_stalled).  The next
+    // sample it hands on makes the stream active again; it continues from its own carried state.
+    std::atomic<int> stall_ms{ 2000 };
+    std::atomic<int> silent{ 0 };
+    std::atomic<uint64_t> stall_events{ 0 };
     std::mutex rec_mu; nvx_wav *rec = nullptr;  // debug recording of what the consumer hands on (capt_sched.c:87-101, 516)
     std::thread worker;
 };
 
 static void capture_consumer(nvx_capture *c)
 {
+    auto last_progress = std::chrono::steady_clock::now();
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(c->cv_mu);
             c->cv.wait_for(lk, std::chrono::milliseconds(50), [&] {     // the reference polls every 50 ms (capt_sched.c:486)
                 return c->stop.load() || (!c->paused.load() && c->head.load() != c->tail.load());
             });
+        }
+        // results of launches that have finished meanwhile: bits and messages reach the user within a poll interval even
+        // when no further launch follows (the last message before the band goes quiet); never waits for the GPU
+        if (int rc = nvx_poll(c->h); rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }
+        const bool idle = c->paused.load() || c->head.load() == c->tail.load();
+        const int limit = c->stall_ms.load();
+        if (idle && !c->stop.load() && !c->silent.load() && limit > 0 &&
+            std::chrono::steady_clock::now() - last_progress > std::chrono::milliseconds(limit)) {
+            if (nvx_stream_set_active(c->h, c->stream, 0) == NVX_OK) { c->silent.store(1); c->stall_events.fetch_add(1); }
         }
         if (c->paused.load() && !c->stop.load()) continue;
         uint64_t t = c->tail.load(), hd = c->head.load();
@@ -38,9 +55,10 @@ static void capture_consumer(nvx_capture *c)
             size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
             size_t took = 0;
             int rc = nvx_push_iq_partial(c->h, c->stream, c->ring.data() + 2 * at, n, &took);
-            // Another stream of the handle is a whole staging set behind (its radio stalled): back-pressure, not an
-            // error.  Keep what was not taken in the ring (its overrun accounting counts any loss) and retry after the
-            // poll interval.  While stopping, a handle that takes nothing for a second is given up on (NVX_ERR_FULL).
+            // NVX_ERR_FULL (only the two-kernel wideband form still produces it: its streams launch together and another
+            // one is a whole staging set behind): back-pressure, not an error.  Keep what was not taken in the ring (its
+            // overrun accounting counts any loss) and retry after the poll interval.  While stopping, a handle that
+            // takes nothing for a second is given up on (NVX_ERR_FULL).
             if (rc == NVX_ERR_FULL) { c->full_waits.fetch_add(1); backoff = true; }
             else if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }      // hard error (HIP): give up, report
             n = took;
@@ -53,6 +71,7 @@ static void capture_consumer(nvx_capture *c)
             t += n;
             c->tail.store(t);
             c->consumed.fetch_add(n);
+            if (n) { last_progress = std::chrono::steady_clock::now(); c->silent.store(0); }     // (the push made the stream active again)
             if (backoff) break;
         }
         if (backoff) {
@@ -137,6 +156,18 @@ extern "C" int nvx_capture_error(nvx_capture *c, uint64_t *full_waits)
     if (!c) return NVX_ERR_ARG;
     if (full_waits) *full_waits = c->full_waits.load();
     return c->error.load();
+}
+
+extern "C" int nvx_capture_stalled(nvx_capture *c, uint64_t *stall_events)
+{
+    if (!c) return NVX_ERR_ARG;
+    if (stall_events) *stall_events = c->stall_events.load();
+    return c->silent.load();
+}
+
+extern "C" void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds)
+{
+    if (c) c->stall_ms.store(seconds > 0 ? (int)(seconds * 1000.0 + 0.5) : 0);
 }
 
 extern "C" int nvx_capture_stop(nvx_capture *c)

@@ -240,10 +240,14 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         if (lane == 0) u = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u = __builtin_amdgcn_readfirstlane(u);
         if (u >= n_units) break;
-        int tpart, thirds, stream;                     // first third of the unit in its stream, thirds it covers (3 = a frame)
-        if (u < n_full) { const int frame = u / a.n_streams; stream = u - frame * a.n_streams; tpart = 3 * frame; thirds = 3; }
-        else { const int v = u - n_full, q = v / a.n_streams; stream = v - q * a.n_streams; tpart = 3 * a.split_from + q; thirds = 1; }
+        int tpart, thirds, entry;                      // first third of the unit in its stream, thirds it covers (3 = a frame)
+        if (u < n_full) { const int frame = u / a.n_streams; entry = u - frame * a.n_streams; tpart = 3 * frame; thirds = 3; }
+        else { const int v = u - n_full, q = v / a.n_streams; entry = v - q * a.n_streams; tpart = 3 * a.split_from + q; thirds = 1; }
         const int part = tpart;                        // (position in the stream, in thirds)
+        // which stream: the launch's list of participants (nvx_kernels.h, nvx_part), or every stream in index order
+        int stream = entry, parity = a.parity;
+        if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); stream = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
+        int *const done = a.done + entry;              // hand-over flag of this stream within the launch
         const unsigned mask = a.chain_masks[stream];
 
         // independent units: rebuild the histories from the nine passes in front of the unit (nvx_kernels.h)
@@ -264,7 +268,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
             int spins = 0, ok = 0;
             do {
                 int d = 0;
-                if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 d = __builtin_amdgcn_readfirstlane(d);
                 ok = d >= part;
                 if (!ok && a.dynamic_preroll) break;
@@ -299,11 +303,11 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
 
         // ------------------------------------------------------ state in
-        // A stream's first unit of a launch reads the block the previous launch left (state_in); every unit
-        // writes state_out, which the host swaps with state_in between launches -- so a launch never reads
-        // and writes the same block through different units (the independent units run in any order).
-        double2 *st = (double2 *)(a.state_out + (size_t)stream * NVX_CASCADE_STATE_BYTES);
-        const double2 *st_in = (part == 0) ? (const double2 *)(a.state_in + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
+        // A stream's first unit of a launch reads the block the stream's previous launch left (state[parity]); every
+        // unit writes the other one, and the host flips the stream's parity behind every launch it took part in -- so
+        // a launch never reads and writes the same block through different units (the independent units run in any order).
+        double2 *st = (double2 *)((parity ? a.state[0] : a.state[1]) + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+        const double2 *st_in = (part == 0) ? (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start; the pre-roll starts
         // 576 = 0 mod 9 outputs earlier: same index); FIR3 outputs of the pre-roll are not written
         cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_THIRD_Y3, a.y3_cap,
@@ -365,7 +369,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
             int spins = 0, ok = 0;
             do {
                 int d = 0;
-                if (lane == 0) d = __hip_atomic_load(a.done + stream, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 d = __builtin_amdgcn_readfirstlane(d);
                 ok = d >= part;
                 if (!ok) __builtin_amdgcn_s_sleep(32);
@@ -389,7 +393,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        if (lane == 0 && !a.independent) __hip_atomic_store(a.done + stream, part + thirds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !a.independent) __hip_atomic_store(done, part + thirds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

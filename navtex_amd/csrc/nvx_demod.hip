@@ -81,7 +81,16 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_a
     __shared__ double s_C[567 + DTL];
     __shared__ unsigned char s_D[DTL];
     __shared__ unsigned s_near, s_evals, s_minm;
-    const int slot = blockIdx.x, tid = threadIdx.x;
+    // block -> chain: every slot, or the slots of the launch's participants (nvx_kernels.h, nvx_part: entry e covers the
+    // decoded streams per_part * stream .. + per_part - 1, two slots each, and carries their common sample count g0)
+    const int tid = threadIdx.x;
+    int slot = blockIdx.x;
+    unsigned long long g0 = a.g0;
+    if (a.part) {
+        const int per = 2 * a.per_part, e = blockIdx.x / per;
+        slot = a.part[e].stream * per + (blockIdx.x - e * per);
+        g0 = a.part[e].g0;
+    }
     if (!a.slot_active[slot]) return;                    // uniform over the block
     if (tid == 0) { s_near = 0; s_evals = 0; s_minm = 0x7f800000u; }
     unsigned my_near = 0, my_evals = 0;
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front(nvx_demod_a
 
     for (int ta = 0; ta < a.n3; ta += DTL) {
         const int tl = min(DTL, a.n3 - ta);
-        const unsigned long long gt = a.g0 + (unsigned long long)ta;     // g of L = 0
+        const unsigned long long gt = g0 + (unsigned long long)ta;       // g of L = 0
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             const int t = ta + L;
             // ---- discriminator, decoder.C:48-52
@@ -232,8 +241,13 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
         for (int i = threadIdx.x; i < NVX_FSM_TABLE_ALLOC / 4; i += 64) dst[i] = src[i];
     }
     __syncthreads();
-    const int slot = blockIdx.x * 64 + threadIdx.x;
+    int slot = blockIdx.x * 64 + threadIdx.x;
     const int nc = a.n_slots;
+    if (a.part) {                                        // the slots of the launch's participants, as in the front kernel
+        const int per = 2 * a.per_part, e = slot / per;
+        if (e >= a.n_part) return;
+        slot = a.part[e].stream * per + (slot - e * per);
+    }
     if (slot >= nc) return;
     if (!a.slot_active[slot]) return;
     int *si = a.state_i;
@@ -285,13 +299,15 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
 
 extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s)
 {
-    hipLaunchKernelGGL(nvx_demod_front, dim3((unsigned)a->n_slots), dim3(NVX_FRONT_THREADS), 0, s, *a);
+    const unsigned chains = a->part ? (unsigned)(2 * a->per_part * a->n_part) : (unsigned)a->n_slots;
+    hipLaunchKernelGGL(nvx_demod_front, dim3(chains), dim3(NVX_FRONT_THREADS), 0, s, *a);
     return hipGetLastError();
 }
 
 extern "C" hipError_t nvx_launch_demod_fsm(const nvx_demod_args *a, hipStream_t s)
 {
-    hipLaunchKernelGGL(nvx_demod_fsm, dim3((unsigned)((a->n_slots + 63) / 64)), dim3(64), 0, s, *a);
+    const int chains = a->part ? 2 * a->per_part * a->n_part : a->n_slots;
+    hipLaunchKernelGGL(nvx_demod_fsm, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, s, *a);
     return hipGetLastError();
 }
 

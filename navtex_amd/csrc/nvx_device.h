@@ -42,6 +42,13 @@ __device__ __forceinline__ void nvx_static_for(F &&f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); nvx_static_for<I + 1, N>(f); }
 }
 
+// A wave-uniform read of launch-constant data (written by the host before the kernel started, never by the kernel):
+// through the constant address space, so that it is a scalar load (s_load) and not a vector load in every lane.
+__device__ __forceinline__ unsigned long long nvx_load_const_u64(const void *p)
+{
+    return *(const __attribute__((address_space(4))) unsigned long long *)(unsigned long long)p;
+}
+
 typedef short nvx_short2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: nontemporal builtin needs it
 

@@ -22,7 +22,8 @@ struct Member {
     nvx_handle *h = nullptr;
     std::vector<uint8_t> masks;
     std::vector<int> labels;
-    std::vector<GroupMsg> parked;                 // written by this member's worker (or the pushing thread), read after a join
+    std::mutex parked_mu;                         // parked: written by whoever runs the member's collect -- its worker, or a thread
+    std::vector<GroupMsg> parked;                 // pushing into one of its streams -- and emptied by the thread that delivers
     // worker
     std::thread worker;
     std::mutex mu; std::condition_variable cv;
@@ -36,12 +37,15 @@ struct nvx_group {
     int total = 0;                                // input streams (wideband: 2.016 MS/s inputs)
     int per_in = 1;                               // decoded streams per input stream: 8 in wideband mode (stream 8 * w + k)
     std::vector<Member *> members;
-    std::mutex api_mu;                            // one API call at a time (the members' handles have their own locks)
+    std::mutex api_mu;                            // one CONTROL call (reset, launch, fetch, flush) at a time.  nvx_group_push_iq does
+                                                  // not take it: capture threads feeding different members run side by side, each
+                                                  // serialised only by its member's own handle lock
 };
 
 static void member_on_message(void *user, int stream, const char *bbbb, const char *message, int freq)
 {
     Member *m = (Member *)user;
+    std::lock_guard<std::mutex> lk(m->parked_mu);
     m->parked.push_back(GroupMsg{ m->g->per_in * m->first + stream, bbbb, message, freq });
 }
 
@@ -88,11 +92,12 @@ static int member_join(Member *m)
 static void deliver_parked(nvx_group *g)
 {
     for (Member *m : g->members) {
-        for (auto &msg : m->parked) {
+        std::vector<GroupMsg> batch;
+        { std::lock_guard<std::mutex> lk(m->parked_mu); batch.swap(m->parked); }     // a pushing thread may park more meanwhile: next delivery
+        for (auto &msg : batch) {
             if (g->cfg.on_message) g->cfg.on_message(g->cfg.user, msg.stream, msg.bbbb.c_str(), msg.text.c_str(), msg.freq);
             else add_message((char *)msg.bbbb.c_str(), (char *)msg.text.c_str(), msg.freq);          // receiver/message_store.h:7
         }
-        m->parked.clear();
     }
 }
 
@@ -187,7 +192,7 @@ extern "C" int nvx_group_reset(nvx_group *g)
     for (Member *m : g->members) member_post(m, [m] { return nvx_reset(m->h); });
     int rc = NVX_OK;
     for (Member *m : g->members) { const int r = member_join(m); if (r != NVX_OK && rc == NVX_OK) rc = r; }
-    for (Member *m : g->members) m->parked.clear();
+    for (Member *m : g->members) { std::lock_guard<std::mutex> pl(m->parked_mu); m->parked.clear(); }
     return rc;
 }
 
@@ -216,9 +221,10 @@ extern "C" int nvx_group_push_iq(nvx_group *g, int s, const int16_t *iq, size_t 
 {
     const int mi = nvx_group_member_of(g, s);
     if (mi < 0) { nvx_set_error("nvx_group_push_iq: no stream %d", s); return NVX_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(g->api_mu);
     Member *m = g->members[mi];
-    // on the caller's thread (a capture thread owns its stream); messages a launch completes meanwhile stay parked
+    // On the caller's thread (a capture thread owns its stream) and WITHOUT the group's lock: the member's handle locks
+    // itself, so N capture threads feeding N members copy into N pinned staging areas at once -- under one group-wide
+    // lock the host-fed rate of eight GPUs was one thread's memcpy rate.  Messages a launch completes meanwhile stay parked.
     return nvx_push_iq(m->h, s - m->first, iq, n);
 }
 

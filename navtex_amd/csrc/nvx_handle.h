@@ -20,6 +20,7 @@
 #include "navtex_amd.h"
 #include "nvx_internal.h"
 #include "nvx_kernels.h"
+#include "nvx_pool.h"
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -51,6 +52,11 @@ struct Slot {                          // one (stream, chain)
 struct Result {                        // one in-flight launch's bit output
     uint8_t *d_bits = nullptr; int *d_nbits = nullptr;
     uint8_t *h_bits = nullptr; int *h_nbits = nullptr;
+    // the input streams that took part in the launch (nvx_kernels.h, nvx_part): pinned host copy, device copy, and
+    // how many -- 0 = every stream (no list); the collect reads bits of the participants' chains only
+    nvx_part *h_part = nullptr, *d_part = nullptr;
+    int n_part = 0;
+    hipEvent_t copied = nullptr;       // push mode: the launch's host-to-device copies have left the staging sets
     hipEvent_t done = nullptr;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
     bool timed = false;
@@ -96,7 +102,13 @@ struct nvx_handle {
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
     int *h_status = nullptr;           // pinned copies of {status, wait polls, units that waited} per result slot
     uint64_t wait_polls = 0, wait_units = 0, wait_launches = 0;   // accumulated at collect
-    unsigned long long g0 = 0;         // 900 S/s samples per chain since reset
+    // Per INPUT stream, advanced by every launch the stream takes part in: which cascade state block it reads next
+    // (it writes the other) and how many 900 S/s samples its chains have been through since reset.  As long as every
+    // launch covered every stream (`diverged` false) all entries are equal and launches need no participant list.
+    std::vector<uint8_t> parity;
+    std::vector<unsigned long long> g0s;
+    bool diverged = false;
+    uint64_t partial_launches = 0;     // launches that covered only some of the streams, since create
     Result res[RESULT_SLOTS];
     uint64_t launched = 0, collected = 0;
     int last_n3 = 0;
@@ -109,12 +121,18 @@ struct nvx_handle {
     std::vector<uint8_t> masks;
     std::vector<Slot> slots;
     std::vector<struct SinkCtx *> sinks;   // user pointers handed to the per-slot character layers
+    HostPool pool;                         // character-layer workers, started on first use
     std::mutex mu;
-    // push mode staging: two pinned sets [n_streams][stage_cap] of packed IQ words
+    // push mode staging: two pinned sets [n_streams][stage_cap] of packed IQ words.  Every stream fills ITS current set
+    // (cur[s]) and flips to the other one when a launch takes frames from it; set_launch[s][k] = 1 + the number of the
+    // launch whose host-to-device copy last read set k of stream s (0 = none), copies_synced = the highest launch
+    // number + 1 whose copy is known to have finished.  active[s] = 0: the stream has gone silent (capture ring's
+    // stall timeout, nvx_stream_set_active) and the lock-step trigger does not wait for it.
     uint32_t *h_stage[2] = { nullptr, nullptr };
-    hipEvent_t stage_free[2] = { nullptr, nullptr };
-    bool stage_busy[2] = { false, false };
-    int cur = 0;
+    std::vector<uint8_t> cur;
+    std::vector<uint64_t> set_launch[2];
+    uint64_t copies_synced = 0;
+    std::vector<uint8_t> active;
     size_t stage_cap = 0;
     std::vector<size_t> fill;
     uint32_t *d_in = nullptr;
@@ -123,8 +141,9 @@ struct nvx_handle {
 struct SinkCtx { nvx_handle *h; int stream; int slot; };
 
 // launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)
+// part / n_part: the input streams that take part, ascending (nullptr = every stream)
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
-                      bool input_on_stream3 = false);
+                      bool input_on_stream3 = false, const int *part = nullptr, int n_part = 0);
 // nvx_push_iq that reports how many samples it staged before NVX_ERR_FULL (or another error) stopped it
 int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted);
 // wideband handles: the fused kernel (default) or channeliser + cascade (NVX_WB_FUSED=0)
@@ -132,6 +151,8 @@ bool nvx_wb_fused();
 // wait for the launched blocks in front of launch number `upto` (default: every one), append bits, run the character
 // layer (handle locked)
 int nvx_collect_locked(nvx_handle *h, uint64_t upto = UINT64_MAX);
+// ... the same for every launched block that has ALREADY finished: never waits (handle locked)
+int nvx_collect_ready_locked(nvx_handle *h);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries
 const uint32_t *nvx_fsm_table_host();
 

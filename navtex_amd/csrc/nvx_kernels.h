@@ -39,16 +39,31 @@
 #define NVX_DI_PHASE       3            /* bit-FSM phase, resets to -1 (waiting)            */
 #define NVX_DI_PREV_OFFSET 4            /* resets to -1 (decoder.C:30)                      */
 
+/* Which streams of a handle a launch covers.  The chains share no state (receiver/decoder.h:31-60,
+ * receiver/nav_b_sm.h:92-114; FIR1 / mixer per stream: receiver/fir1cpp.C:57-60, receiver/fir2cpp.C:74-83), so nothing ties
+ * the streams of one handle to a common clock: a launch names the streams that HAVE a frame (a radio that stalls or is
+ * unplugged -- receiver/capt_sched.c:210-212 only prints sdrplay_api_DeviceRemoved -- must not freeze the others).
+ * One entry per participating stream; a NULL list = every stream, in index order, with the launch-wide parity and g0.
+ * Rows of every per-stream buffer (input, state blocks, y3, words, bits) are indexed by `stream`; the work queue's
+ * done[] and the unit numbering by the entry's position in the list.                                              */
 typedef struct {
-    const uint32_t *iq;        /* [n_streams][pitch] packed int16 I | Q<<16            */
+    int stream;                /* stream index (input stream: a wideband handle's 2.016 MS/s stream)             */
+    int parity;                /* the stream reads state block [parity] and writes [parity ^ 1]                  */
+    unsigned long long g0;     /* 900 S/s samples the stream has been through since reset (multiple of 288)      */
+} nvx_part;
+
+typedef struct {
+    const uint32_t *iq;        /* [all streams][pitch] packed int16 I | Q<<16          */
     size_t pitch;              /* complex samples between streams                      */
     size_t first_sample;       /* first complex sample of this launch in every stream  */
     int n_frames;
-    int n_streams;
+    int n_streams;             /* streams taking part in this launch                   */
+    const nvx_part *part;      /* [n_streams], or NULL: streams 0 .. n_streams-1, parity `parity` */
+    int parity;
     const uint8_t *chain_masks;
-    const uint8_t *state_in;   /* [n_streams][NVX_CASCADE_STATE_BYTES] left by the previous launch */
-    uint8_t *state_out;        /* same layout; hand-over inside this launch and to the next one   */
-    double2 *y3;               /* [n_streams*2][y3_cap]                                */
+    uint8_t *state[2];         /* [all streams][NVX_CASCADE_STATE_BYTES] each: a stream's launch reads [its parity] (left by ITS */
+                               /* previous launch) and writes the other; hand-over inside the launch goes through the written one */
+    double2 *y3;               /* [all streams*2][y3_cap]                              */
     size_t y3_cap, y3_base;
     int *queue;                /* NVX_CASCADE_CTRL_INTS control ints followed by ...   */
     int *status;               /* = queue + 1                                          */
@@ -75,9 +90,12 @@ typedef struct {
     const double2 *y3;
     size_t y3_cap, y3_base;
     int n3;                    /* 900 S/s samples in this launch                       */
-    int n_slots;               /* n_streams * 2                                        */
+    int n_slots;               /* all streams * 2                                      */
     const uint8_t *slot_active;
-    unsigned long long g0;     /* 900 S/s samples processed since reset (multiple of 288) */
+    unsigned long long g0;     /* 900 S/s samples processed since reset (multiple of 288); part != NULL: per entry */
+    const nvx_part *part;      /* participating streams of this launch, or NULL = all  */
+    int n_part;                /* entries of part                                      */
+    int per_part;              /* decoded streams per entry: 8 on a wideband handle (stream 8 * w + k), else 1 */
     double *dstate;            /* [n_slots][NVX_DEMOD_DOUBLES]                         */
     int *state_i;              /* [field][n_slots]                                     */
     const uint32_t *fsm_table; /* NVX_FSM_TABLE_ALLOC entries (nvx_fsm.h), 16-byte aligned */
@@ -110,14 +128,16 @@ typedef struct {
 typedef struct {
     const uint32_t *raw;       /* [n_wide][pitch] packed IQ at 2.016 MS/s                                    */
     size_t pitch, first_sample;
-    int n_wide, n_frames;
-    const uint8_t *chain_masks;/* [8 * n_wide]                                                               */
-    const uint8_t *state_in;   /* cascade state blocks of the 8 * n_wide decoded streams, as nvx_cascade_args */
-    uint8_t *state_out;
-    const uint32_t *hist_in;   /* [n_wide][40] raw words in front of first_sample (NULL = silence)           */
-    uint32_t *hist_out;        /* [n_wide][40]: hand-over inside this launch and to the next one             */
+    int n_wide, n_frames;      /* n_wide: wideband streams taking part in this launch                         */
+    const nvx_part *part;      /* [n_wide], or NULL: streams 0 .. n_wide-1 with parity `parity`               */
+    int parity;
+    const uint8_t *chain_masks;/* [8 * all wideband streams]                                                  */
+    uint8_t *state[2];         /* cascade state blocks of the decoded streams, as nvx_cascade_args            */
+    uint32_t *hist[2];         /* [all wideband streams][40] raw words in front of the launch: read [parity], */
+                               /* written [parity ^ 1] (hand-over inside this launch and to the next one)     */
     double2 *y3; size_t y3_cap, y3_base;
     int *queue, *status, *done;/* as nvx_cascade_args; done[n_wide]                                          */
+    int independent;           /* set by the launcher: units pre-roll instead of waiting for their predecessor */
 } nvx_wideband_args;
 
 #ifdef __cplusplus

@@ -1,41 +1,84 @@
-// nvx_push.cpp -- host-input path: pinned staging sets, hipMemcpyAsync to the device, launches
-// whenever every stream has a whole frame; the WAV file path on top of it.
+// nvx_push.cpp -- host-input path: pinned staging sets, hipMemcpyAsync to the device, launches whenever every active
+// stream has a whole frame (or one stream cannot wait any longer); the WAV file path on top of it.
 #include "nvx_handle.h"
 
 // ------------------------------------------------------- host-input path
-// Submit the largest common whole-frame prefix of the current staging set.
+// The streams of a handle are independent receivers (receiver/decoder.h:31-60, receiver/nav_b_sm.h:92-114): nothing ties
+// them to a common clock.  Normally they advance together -- a launch goes out when every ACTIVE stream has a whole
+// frame staged, and covers all of them.  A stream that falls behind (its radio stalled, was unplugged --
+// receiver/capt_sched.c:210-212 only prints sdrplay_api_DeviceRemoved -- or simply runs a few ppm slow) does not hold
+// the others: when a stream's staging is full, the launch goes out with the streams that HAVE a frame, each from its
+// own carried state; the late one joins a later launch and continues bit-exactly from where it stopped.
+static int n_whole_frames(const nvx_handle *h, int s) { return (int)(h->fill[s] / h->frame_in); }
+
+// every active stream has a whole frame (and there is at least one active stream)
+static bool lockstep_ready(const nvx_handle *h)
+{
+    bool any = false;
+    for (int s = 0; s < h->n_in; s++) {
+        if (!h->active[s]) continue;
+        if (h->fill[s] < h->frame_in) return false;
+        any = true;
+    }
+    return any;
+}
+
+// Launch the streams that have at least one whole frame staged, with as many frames as all of THEM have.
 static int submit_locked(nvx_handle *h)
 {
-    size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
-    int frames = (int)std::min<size_t>(minfill / h->frame_in, (size_t)h->cfg.max_frames);
-    if (frames < 1) return NVX_OK;
-    const int cur = h->cur, nxt = cur ^ 1;
+    std::vector<int> part;
+    int frames = h->cfg.max_frames;
+    for (int s = 0; s < h->n_in; s++) {
+        const int f = n_whole_frames(h, s);
+        if (f < 1) continue;
+        part.push_back(s);
+        frames = std::min(frames, f);
+    }
+    if (part.empty()) return NVX_OK;
+    const bool on_stream3 = h->cfg.wideband && !nvx_wb_fused();
+    if (on_stream3 && (int)part.size() != h->n_in) return NVX_OK;      // the two-kernel wideband form launches all streams together
     const size_t take = (size_t)frames * h->frame_in;
     const size_t dpitch = (size_t)h->cfg.max_frames * h->frame_in;
-    // the other staging set must have left the copy engine before it is refilled
-    if (h->stage_busy[nxt]) { HIP_TRY(hipEventSynchronize(h->stage_free[nxt])); h->stage_busy[nxt] = false; }
+    // a participant flips to its other staging set: that set must have left the copy engine (it was read by the copy
+    // of the stream's previous launch; copies run in launch order on one stream, so one wait covers everything older)
+    uint64_t need = 0;
+    for (int s : part) need = std::max(need, h->set_launch[h->cur[s] ^ 1][s]);
+    if (need > h->copies_synced) {
+        // (a result slot reused since then carries a LATER copy's event: waiting for that covers the older one too)
+        HIP_TRY(hipEventSynchronize(h->res[(need - 1) % RESULT_SLOTS].copied));
+        h->copies_synced = need;
+    }
     // d_in is reused by every launch: stream order makes its previous reader finish first (the cascade or the fused
     // wideband kernel on h->stream; in the two-kernel wideband form the channeliser on stream3, which is why the copy
-    // goes there then)
-    const bool on_stream3 = h->cfg.wideband && !nvx_wb_fused();
+    // goes there then).  Runs of neighbouring participants that fill the same set go as one 2-D copy.
     hipStream_t cs = on_stream3 ? h->stream3 : h->stream;
-    HIP_TRY(hipMemcpy2DAsync(h->d_in, dpitch * 4, h->h_stage[cur], h->stage_cap * 4, take * 4, (size_t)h->n_in,
-                             hipMemcpyHostToDevice, cs));
-    HIP_TRY(hipEventRecord(h->stage_free[cur], cs));
-    h->stage_busy[cur] = true;
-    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, on_stream3);
-    if (rc != NVX_OK) return rc;
-    // carry what was not submitted over to the other set
-    for (int s = 0; s < h->n_in; s++) {
-        size_t rest = h->fill[s] - take;
-        if (rest) memcpy(h->h_stage[nxt] + (size_t)s * h->stage_cap, h->h_stage[cur] + (size_t)s * h->stage_cap + take, rest * 4);
-        h->fill[s] = rest;
+    for (size_t i = 0; i < part.size();) {
+        size_t j = i + 1;
+        while (j < part.size() && part[j] == part[j - 1] + 1 && h->cur[part[j]] == h->cur[part[i]]) j++;
+        const int s0 = part[i];
+        HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)s0 * dpitch, dpitch * 4, h->h_stage[h->cur[s0]] + (size_t)s0 * h->stage_cap, h->stage_cap * 4,
+                                 take * 4, j - i, hipMemcpyHostToDevice, cs));
+        i = j;
     }
-    h->cur = nxt;
+    Result &r = h->res[h->launched % RESULT_SLOTS];
+    HIP_TRY(hipEventRecord(r.copied, cs));           // (re-recording an event a later wait may still name: see above)
+    const uint64_t this_launch = h->launched + 1;
+    const bool all = (int)part.size() == h->n_in;
+    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, on_stream3, all ? nullptr : part.data(), all ? 0 : (int)part.size());
+    if (rc != NVX_OK) return rc;
+    // what was not submitted moves over to the participant's other set, which it fills from now on
+    for (int s : part) {
+        const int c = h->cur[s], n = c ^ 1;
+        h->set_launch[c][s] = this_launch;
+        const size_t rest = h->fill[s] - take;
+        if (rest) memcpy(h->h_stage[n] + (size_t)s * h->stage_cap, h->h_stage[c] + (size_t)s * h->stage_cap + take, rest * 4);
+        h->fill[s] = rest;
+        h->cur[s] = (uint8_t)n;
+    }
     return NVX_OK;
 }
 
-// accepted (optional): how many of the n samples were staged -- all of them on NVX_OK, fewer on NVX_ERR_FULL
+// accepted (optional): how many of the n samples were staged -- all of them on NVX_OK, fewer on an error
 template <typename F>
 static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *accepted = nullptr)
 {
@@ -44,25 +87,26 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (n) h->active[stream] = 1;                    // a stream that delivers is (again) one the others wait for
     size_t done = 0;
     while (done < n) {
         size_t room = h->stage_cap - h->fill[stream];
         if (room == 0) {
+            // this stream is max_frames + 1 frames ahead of a launch: go with the streams that have a frame
             int rc = submit_locked(h);
-            if (rc != NVX_OK) return rc;
+            if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
             room = h->stage_cap - h->fill[stream];
-            if (room == 0) {
+            if (room == 0) {                         // only the two-kernel wideband form gets here
                 nvx_set_error("stream %d is a whole staging buffer ahead of the slowest stream", stream);
                 if (accepted) *accepted = done;
                 return NVX_ERR_FULL;
             }
         }
         size_t m = std::min(room, n - done);
-        copy_in(h->h_stage[h->cur] + (size_t)stream * h->stage_cap + h->fill[stream], done, m);
+        copy_in(h->h_stage[h->cur[stream]] + (size_t)stream * h->stage_cap + h->fill[stream], done, m);
         h->fill[stream] += m;
         done += m;
-        size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
-        if (minfill >= h->frame_in) { int rc = submit_locked(h); if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; } }
+        if (lockstep_ready(h)) { int rc = submit_locked(h); if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; } }
     }
     if (accepted) *accepted = n;
     return NVX_OK;
@@ -93,11 +137,12 @@ extern "C" int nvx_flush(nvx_handle *h)
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->cfg.push_mode) {
+        // whatever is staged in whole frames goes out, stream by stream as far as each has got
         for (;;) {
-            size_t minfill = *std::min_element(h->fill.begin(), h->fill.end());
-            if (minfill < h->frame_in) break;
+            const uint64_t before = h->launched;
             int rc = submit_locked(h);
             if (rc != NVX_OK) return rc;
+            if (h->launched == before) break;
         }
     }
     return nvx_collect_locked(h);
@@ -137,4 +182,27 @@ extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
     rc = nvx_flush(h);
     if (rc != NVX_OK) return rc;
     return (int)((total + h->frame_in - 1) / h->frame_in);
+}
+
+// ------------------------------------------------------------------ stream activity
+extern "C" int nvx_stream_set_active(nvx_handle *h, int stream, int active)
+{
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_set_active: bad stream"); return NVX_ERR_ARG; }
+    if (!h->cfg.push_mode) { nvx_set_error("nvx_stream_set_active: handle was not created with push_mode"); return NVX_ERR_STATE; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    h->active[stream] = active ? 1 : 0;
+    // the others may have been waiting for exactly this stream
+    if (!active && lockstep_ready(h)) return submit_locked(h);
+    return NVX_OK;
+}
+
+extern "C" int nvx_stream_stats(nvx_handle *h, int stream, int *active, uint64_t *frames_done, uint64_t *partial_launches)
+{
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_stats: bad stream"); return NVX_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (active) *active = h->active.empty() ? 1 : (int)h->active[stream];
+    if (frames_done) *frames_done = h->g0s[stream] / NVX_FRAME_Y3;
+    if (partial_launches) *partial_launches = h->partial_launches;
+    return NVX_OK;
 }

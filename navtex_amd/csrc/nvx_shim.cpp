@@ -35,6 +35,29 @@ static void shim_fatal(const char *what)
     abort();                                     // void reference entry points cannot report errors
 }
 
+// Housekeeping for the singleton: every 50 ms (the reference's own poll interval, capt_sched.c:486) take in what the GPU
+// has finished, so that a message completes at add_message although no further sample arrives (nvx_poll never waits).
+static std::thread g_keeper;
+static std::atomic<bool> g_keeper_stop{ false };
+static std::mutex g_keeper_mu; static std::condition_variable g_keeper_cv;
+static void keeper_stop(void)
+{
+    { std::lock_guard<std::mutex> lk(g_keeper_mu); g_keeper_stop.store(true); }
+    g_keeper_cv.notify_all();
+    if (g_keeper.joinable()) g_keeper.join();
+}
+static void keeper_loop(nvx_handle *h)
+{
+    std::unique_lock<std::mutex> lk(g_keeper_mu);
+    while (!g_keeper_stop.load()) {
+        g_keeper_cv.wait_for(lk, std::chrono::milliseconds(50));
+        if (g_keeper_stop.load()) break;
+        lk.unlock();
+        if (nvx_poll(h) != NVX_OK) { fprintf(stderr, "navtex_amd: housekeeping: %s\n", nvx_last_error()); lk.lock(); break; }
+        lk.lock();
+    }
+}
+
 static void shim_require(void)
 {
     if (g_shim) return;
@@ -43,6 +66,10 @@ static void shim_require(void)
     c.max_frames = 4; c.char_layer = 1; c.push_mode = 1;
     if (const char *d = getenv("NAVTEX_AMD_DEVICE")) c.device = atoi(d);
     if (nvx_create(&c, &g_shim) != NVX_OK) shim_fatal("cannot create the GPU pipeline");
+    if (!(getenv("NAVTEX_AMD_NO_KEEPER") && atoi(getenv("NAVTEX_AMD_NO_KEEPER")))) {
+        g_keeper = std::thread(keeper_loop, g_shim);
+        atexit(keeper_stop);                       // joined before the HIP runtime (loaded earlier) tears down
+    }
 }
 
 static void shim_drain(void)

@@ -18,8 +18,14 @@
 // Two workgroup barriers per pass.  Filter histories and the 40-sample halo travel from unit (w, f) to (w, f+1)
 // through HBM exactly as in the cascade kernel: sc1 accesses, every storing wave drains (vmcnt 0), workgroup
 // barrier, one lane sets done[w]; the consumer's lane 0 polls, workgroup barrier, sc1 loads (MI355X_MICROARCH.md,
-// "Valid forms", first row).  Launches of few streams run their units one after the other (there is no pre-roll form
-// here); the grid is one workgroup per CU (LDS: 151 KB).
+// "Valid forms", first row).  The grid is one workgroup per CU (LDS: 151 KB).
+// Few streams (r3): with fewer wideband streams than resident workgroups -- the physically real case is ONE RSP's
+// 2.016 MS/s capture replayed from a recording, receiver/capt_sched.c:356-417 -- the frames of a stream would run one
+// after the other on 1 of 256 CUs.  The launcher then makes the units INDEPENDENT, as the cascade kernel does
+// (nvx_kernels.h): a unit that is not the first of its stream in the launch starts nine passes early, from silence,
+// with the real 40-sample channeliser halo in front of those passes; by its first real pass every filter history holds
+// exactly what the hand-over would have delivered (the horizon argument of nvx_kernels.h: 2153 < 2304 sub-band
+// samples, every batch counter back at 0), so the results are bit-identical; +2.9 % input.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -63,22 +69,28 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         const int u = L.unit;
         if (u >= n_units) break;
         const int part = u / a.n_wide;                  // frame of the launch
-        const int w = u - part * a.n_wide;              // wideband stream
+        const int entry = u - part * a.n_wide;          // position in the launch's list of participants (nvx_kernels.h, nvx_part)
+        int w = entry, parity = a.parity;               // wideband stream, and which of its state blocks it reads
+        if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); w = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
+        int *const done = a.done + entry;
         const int s = NVX_WB_SUBBANDS_K * w + wave;     // decoded 252 kS/s stream of this wave
         const unsigned mask = a.chain_masks[s];
 
+        // independent units: rebuild the histories from the nine passes in front of the unit (above)
+        const bool preroll = a.independent && part > 0;
+        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
         // the input does not depend on the predecessor: request this wave's piece of the first pass now
-        const u32x4 *src = (const u32x4 *)(a.raw + ((size_t)w * a.pitch + a.first_sample) + (size_t)part * NVX_PASSES_PER_FRAME * WB_PASS_WORDS)
-                           + wave * 64 + lane;
+        const uint32_t *unit0 = a.raw + ((size_t)w * a.pitch + a.first_sample) + ((size_t)part * NVX_PASSES_PER_FRAME - (size_t)pre) * WB_PASS_WORDS;
+        const u32x4 *src = (const u32x4 *)unit0 + wave * 64 + lane;
         u32x4 pf = __builtin_nontemporal_load(src);
 
         // ------------------------------------------------------ wait for (w, part-1)
-        if (part > 0) {
+        if (part > 0 && !a.independent) {
             if (wave == 0) {                            // wave-uniform; lane 0 polls, the whole wave agrees on the answer
                 int spins = 0, ok = 0;
                 do {
                     int d = 0;
-                    if (lane == 0) d = __hip_atomic_load(a.done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     d = __builtin_amdgcn_readfirstlane(d);
                     ok = d >= part;
                     if (!ok) __builtin_amdgcn_s_sleep(32);
@@ -95,20 +107,30 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         }
 
         // ------------------------------------------------------ state in (sc1 loads)
-        double2 *st = (double2 *)(a.state_out + (size_t)s * NVX_CASCADE_STATE_BYTES);
-        const double2 *st_in = (part == 0) ? (const double2 *)(a.state_in + (size_t)s * NVX_CASCADE_STATE_BYTES) : st;
-        cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_Y3_PER_FRAME, a.y3_cap, 0, 0, 0, true);
-        cw.state_in(st_in);
+        double2 *st = (double2 *)((parity ? a.state[0] : a.state[1]) + (size_t)s * NVX_CASCADE_STATE_BYTES);
+        const double2 *st_in = (part == 0) ? (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)s * NVX_CASCADE_STATE_BYTES) : st;
+        // (a frame starts at mixer index 0, and so does a pre-roll: 9 * 64 = 0 mod 9; FIR3 outputs of the pre-roll are not written)
+        cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_Y3_PER_FRAME, a.y3_cap, 0,
+                      preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
+        NVX_WAVE_LDS_FENCE();
+        if (!preroll) cw.state_in(st_in); else cw.state_zero();
+        NVX_WAVE_LDS_FENCE();
         if (wave == 0 && lane < 40) {
-            const uint32_t *hin = (part == 0) ? a.hist_in : a.hist_out;
-            L.raw[lane] = hin ? __hip_atomic_load(hin + (size_t)w * 40 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (preroll) {
+                L.raw[lane] = unit0[lane - 40];         // the real samples in front of the pre-roll (this launch's own input)
+            } else {
+                const uint32_t *hin = (((part == 0) == (parity == 0)) ? a.hist[0] : a.hist[1]);
+                L.raw[lane] = __hip_atomic_load(hin + (size_t)w * 40 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
 
-        for (int pass = 0; pass < NVX_PASSES_PER_FRAME; pass++) {
+        const int n_pass = pre + NVX_PASSES_PER_FRAME;
+        for (int pass = 0; pass < n_pass; pass++) {
+            if (pass == pre) { cw.emit = true; cw.n3_done = 0; }
             // ---- 1. this wave's 1 KiB of the pass into the raw window; next pass's piece requested
             *(u32x4 *)&L.raw[40 + 256 * wave + 4 * lane] = pf;
             src += WB_PASS_WORDS / 4;
-            if (pass + 1 < NVX_PASSES_PER_FRAME) pf = __builtin_nontemporal_load(src);
+            if (pass + 1 < n_pass) pf = __builtin_nontemporal_load(src);
             __syncthreads();                            // raw window complete; every wave is done with the last pass's windows
             // ---- 2. channeliser: every wave 32 instants, a lane pair per instant (one component each); instant m's
             //         48-word window is raw[8m .. 8m+47]
@@ -127,15 +149,18 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         }
 
         // ------------------------------------------------------ state out (sc1 stores), publish
+        // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
-        cw.state_out(st);
-        if (wave == 7 && lane < 40 && a.hist_out)
-            __hip_atomic_store(a.hist_out + (size_t)w * 40 + lane, L.raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!a.independent || part + 1 == a.n_frames) {
+            cw.state_out(st);
+            if (wave == 7 && lane < 40)
+                __hip_atomic_store((parity ? a.hist[0] : a.hist[1]) + (size_t)w * 40 + lane, L.raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains ...
         __syncthreads();                                            // ... before the one lane that signals for all of them
         // (the whole of wave 0 stores the same word: a lane-divergent store here is merged with the dequeue at the top of
         // the loop into one "lane 0" region around the back-edge -- the deadlock described there)
-        if (wave == 0) __hip_atomic_store(a.done + w, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && !a.independent) __hip_atomic_store(done, part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -166,6 +191,11 @@ extern "C" hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipS
     if (e != hipSuccess) return e;
     const long long units = (long long)a->n_wide * a->n_frames;
     const unsigned grid = (unsigned)(units < resident ? units : resident);
-    hipLaunchKernelGGL(nvx_wideband_fused, dim3(grid), dim3(512), 0, s, *a);
+    // Fewer streams than resident workgroups: independent units (pre-roll instead of hand-over), all frames at once.
+    // NVX_INDEPENDENT=0/1 forces the choice (tests, A/B runs), as for the cascade kernel.
+    nvx_wideband_args args = *a;
+    static const int force = getenv("NVX_INDEPENDENT") ? atoi(getenv("NVX_INDEPENDENT")) : -1;
+    args.independent = force >= 0 ? force : (a->n_wide < resident && a->n_frames > 1);
+    hipLaunchKernelGGL(nvx_wideband_fused, dim3(grid), dim3(512), 0, s, args);
     return hipGetLastError();
 }

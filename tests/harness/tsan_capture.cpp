@@ -45,6 +45,10 @@ int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, 
     return full ? NVX_ERR_FULL : NVX_OK;
 }
 extern "C" int nvx_flush(nvx_handle *) { return NVX_OK; }
+extern "C" int nvx_poll(nvx_handle *) { return NVX_OK; }                 // the consumer's every-wake "take in what has finished"
+// the consumer's silent-radio report (nvx_capture.cpp: stall timeout) lands here
+static std::atomic<int> g_marked_inactive{ 0 };
+extern "C" int nvx_stream_set_active(nvx_handle *, int, int active) { if (!active) g_marked_inactive++; return NVX_OK; }
 
 int main(int argc, char **argv)
 {

@@ -52,10 +52,15 @@ extern "C" int nvx_process_resident(nvx_handle *h, const void *, size_t, size_t,
 extern "C" int nvx_fetch_bits(nvx_handle *h) { std::lock_guard<std::mutex> lk(h->mu); Stand &s = stand(h); deliver(h, s, s.launched); return NVX_OK; }
 extern "C" int nvx_flush(nvx_handle *h) { return nvx_fetch_bits(h); }
 extern "C" int nvx_reset(nvx_handle *h) { std::lock_guard<std::mutex> lk(h->mu); Stand &s = stand(h); s.launched = s.delivered = 0; return NVX_OK; }
+static std::atomic<int> g_in_push{ 0 }, g_overlapped{ 0 };                  // how many pushes are inside a handle at once
 extern "C" int nvx_push_iq(nvx_handle *h, int stream, const int16_t *, size_t)
 {
     std::lock_guard<std::mutex> lk(h->mu);
     if (stream < 0 || stream >= h->n_streams) return NVX_ERR_ARG;
+    // two members' pushes in flight together = the group does not serialise them
+    if (g_in_push.fetch_add(1) > 0) g_overlapped.fetch_add(1);
+    std::this_thread::sleep_for(std::chrono::microseconds(200));      // "memcpy into pinned staging"
+    g_in_push.fetch_sub(1);
     h->cfg.on_message(h->cfg.user, stream, "PU01", "pushed", 490);      // a push that completes a message on the caller's thread
     return NVX_OK;
 }
@@ -94,6 +99,14 @@ int main()
     std::thread pusher([&] {                   // a capture thread pushing into streams of every member
         for (int i = 0; i < 400; i++) { int16_t iq[2] = { 0, 0 }; if (nvx_group_push_iq(g, (i * 7) % total, iq, 1) != NVX_OK) push_errors++; }
     });
+    // ... and one capture thread PER MEMBER, each feeding only its own member's streams: nvx_group_push_iq holds no
+    // group-wide lock, so these run side by side (and beside the launches, fetches and the deliveries of parked messages)
+    std::vector<std::thread> member_pushers;
+    for (int m = 0; m < n_members; m++)
+        member_pushers.emplace_back([&, m] {
+            int f = 0, c = 0; nvx_group_member(g, m, nullptr, &f, &c, nullptr);
+            for (int i = 0; i < 150; i++) { int16_t iq[2] = { 0, 0 }; if (nvx_group_push_iq(g, f + i % c, iq, 1) != NVX_OK) push_errors++; }
+        });
     const int rounds = 120, per_round = 3;
     int rc_fail = 0;
     for (int r = 0; r < rounds; r++) {
@@ -110,6 +123,7 @@ int main()
         }
     }
     pusher.join();
+    for (auto &t : member_pushers) t.join();
     if (nvx_group_flush(g) != NVX_OK) return 6;
     stop = true; poller.join();
 
@@ -125,9 +139,12 @@ int main()
 
     // launches: rounds * per_round on 4 members + (1 failed on member 1 -> 3 members) + 1 more on all; one message per stream each
     const uint64_t want = (uint64_t)rounds * per_round * total + (uint64_t)(total - 9) + (uint64_t)total;
-    printf("launch messages %llu (want %llu), pushed %llu (want 400), bad %d, fetch errors %d\n",
-           (unsigned long long)seen.launches, (unsigned long long)want, (unsigned long long)seen.pushes, seen.bad, rc_fail);
-    if (seen.launches != want || seen.pushes != 400 || seen.bad || rc_fail || push_errors) return 10;
+    const uint64_t want_pushes = 400 + 150 * (uint64_t)n_members;
+    printf("launch messages %llu (want %llu), pushed %llu (want %llu), overlapping pushes %d, bad %d, fetch errors %d\n",
+           (unsigned long long)seen.launches, (unsigned long long)want, (unsigned long long)seen.pushes, (unsigned long long)want_pushes,
+           g_overlapped.load(), seen.bad, rc_fail);
+    if (seen.launches != want || seen.pushes != want_pushes || seen.bad || rc_fail || push_errors) return 10;
+    if (g_overlapped.load() == 0) return 11;       // pushes into different members really ran at the same time
     printf("tsan group ok\n");
     return 0;
 }

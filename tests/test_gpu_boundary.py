@@ -220,11 +220,9 @@ def test_error_paths(nv):
     with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=1, push_mode=True) as p:
         blk = np.zeros((nv.FRAME_IN, 2), dtype=np.int16)
         p.push(0, blk); p.push(0, blk)                 # staging holds max_frames + 1 frames per stream
-        with pytest.raises(nv.NvxError) as e:
-            p.push(0, blk)                              # stream 1 never delivered: stream 0 may not run further ahead
-        assert e.value.code == -7                      # NVX_ERR_FULL
-        p.push(1, blk); p.push(1, blk)                 # the lagging stream catches up -> launches happen
-        p.push(0, blk)
+        p.push(0, blk)                                  # stream 1 never delivered: since round 3 stream 0 goes on without it
+        assert p.stream_stats(0)[1] >= 1 and p.stream_stats(1)[1] == 0 and p.stream_stats(0)[2] >= 1
+        p.push(1, blk); p.push(1, blk); p.push(1, blk) # the lagging stream catches up
         p.flush()
         assert p.bit_count(0, 0) == p.bit_count(1, 0)
     with pytest.raises(nv.NvxError):

@@ -57,3 +57,15 @@ def test_group_is_clean_under_tsan(tmp_path):
                          env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "tsan group ok" in out.stdout
+
+
+def test_host_pool_is_clean_under_tsan(tmp_path):
+    """ThreadSanitizer over the persistent character-layer workers of a handle (nvx_pool.h): 3000 runs of changing width,
+    every index exactly once, plain writes of the jobs visible to the caller afterwards (tests/harness/tsan_pool.cpp)."""
+    exe = tmp_path / "tsan_pool"
+    csrc = ROOT / "navtex_amd" / "csrc"
+    subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", f"-I{csrc}", str(ROOT / "tests" / "harness" / "tsan_pool.cpp"),
+                    "-o", str(exe), "-lpthread"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "tsan pool ok" in out.stdout

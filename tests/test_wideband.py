@@ -278,6 +278,53 @@ def test_fused_kernel_unit_hand_over_chain(nv, oracle):
 
 
 @pytest.mark.gpu
+def test_fused_dependent_and_independent_units_agree_bit_for_bit(nv, tmp_path):
+    """The fused wideband kernel's two unit forms (r3): hand-over from frame to frame (many streams) and independent units
+    that pre-roll nine passes with the real channeliser halo in front (few streams -- ONE RSP capture replayed from a
+    recording is the physically real case, receiver/capt_sched.c:356-417).  Forced either way in a subprocess: the
+    900 S/s output and the bits of a 29-frame + 19-frame pair of launches of ONE wideband stream are identical, and the
+    independent form is what makes that workload use more than one CU (>= 10 x faster; measured ~40 x)."""
+    import hashlib, json, os, subprocess, sys
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, hashlib, json, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv, signals
+W, F = 1, 48
+n = F * nv.FRAME_RAW
+car = [dict(freq_hz=(k * 252000 if k < 4 else (k - 8) * 252000) + off, bits=nv.sitor_encode(f"ZCZC IU{k}{c}\\nREPLAY\\nNNNN\\n", 10),
+            bit_offset=1000 * k + 77 * c + 1, phase0=k * 999 + c, amplitude=1500) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
+buf = nv.DeviceBuffer(W * n * 4)
+nv.synth_device([nv.make_stream(car, seed=9, noise_amp=700)], nv.RATE_RAW, n, buf, n)
+h = hashlib.sha256()
+with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=29, char_layer=False) as p:
+    p.process_resident(buf, n, 0, 29); p.fetch()                  # warm-up + first half
+    for s in range(8):
+        for c in range(2): h.update(p.debug_y3(s, c).tobytes())
+    p.process_resident(buf, n, 29, 19); p.fetch()
+    for s in range(8):
+        for c in range(2):
+            h.update(p.debug_y3(s, c).tobytes()); h.update(p.bits(s, c).encode())
+    nbits = sum(len(p.bits(s, c)) for s in range(8) for c in range(2))
+    p.reset(); p.enable_timing(True); p.kernel_time_stats(0, reset=True)
+    for _ in range(3):
+        p.process_resident(buf, n, 0, 29)
+    p.fetch()
+    ms, k = p.kernel_time_stats(0)
+print(json.dumps({"digest": h.hexdigest(), "kernel_ms": ms / k, "bits": nbits}))
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    recs = []
+    for force in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, NVX_INDEPENDENT=force))
+        assert out.returncode == 0, out.stderr[-2000:]
+        recs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert recs[0]["digest"] == recs[1]["digest"] and recs[0]["bits"] > 16 * 1000
+    print(f"one wideband stream x 29 frames: hand-over {recs[0]['kernel_ms']:.2f} ms, independent units {recs[1]['kernel_ms']:.2f} ms")
+    assert recs[1]["kernel_ms"] * 10 < recs[0]["kernel_ms"]
+
+
+@pytest.mark.gpu
 def test_group_of_wideband_handles(nv, oracle):
     """Wideband inputs sharded over group members: 3 wideband streams over 2 members (2 + 1), masks and labels per decoded
     stream (8 per input), global ids in the messages."""
