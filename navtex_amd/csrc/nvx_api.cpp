@@ -357,8 +357,10 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->cfg.wideband ? h->n_streams : n_here; ca.chain_masks = h->d_masks;
-    ca.part = h->cfg.wideband ? nullptr : d_list; ca.parity = (int)h->parity[0];
-    ca.state[0] = h->d_cstate[0]; ca.state[1] = h->d_cstate[1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+    ca.part = h->cfg.wideband ? nullptr : d_list;
+    // without a list every stream has the same parity: the kernels then read state[0] and write state[1]
+    const int p0 = d_list ? 0 : (int)h->parity[0];
+    ca.state[0] = h->d_cstate[p0]; ca.state[1] = h->d_cstate[p0 ^ 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
     ca.stage0_order = h->cfg.stage0_order;
@@ -378,9 +380,9 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
         nvx_wideband_args wa{};
         wa.raw = (const uint32_t *)d_wide; wa.pitch = wide_pitch; wa.first_sample = wide_first;
         wa.n_wide = n_here; wa.n_frames = n_frames; wa.chain_masks = h->d_masks;
-        wa.part = d_list; wa.parity = (int)h->parity[0];
-        wa.state[0] = h->d_cstate[0]; wa.state[1] = h->d_cstate[1];
-        wa.hist[0] = h->d_whist[0]; wa.hist[1] = h->d_whist[1];             // a stream reads [its parity], writes the other
+        wa.part = d_list;
+        wa.state[0] = ca.state[0]; wa.state[1] = ca.state[1];
+        wa.hist[0] = h->d_whist[p0]; wa.hist[1] = h->d_whist[p0 ^ 1];       // a stream reads [its parity], writes the other
         wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
         wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done;
         HIP_TRY(nvx_launch_wideband_fused(&wa, st));

@@ -205,7 +205,11 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // sits in a scalar register from the first instruction on.  Same results, different register allocation -- measured on
 // one box, interleaved: raw-rate kernel 20.28 / 20.39 ms by reference against 20.76 / 20.86 by value; the 252 kS/s kernel
 // showed nothing beyond its run-to-run spread, so its code stays as it was (DESIGN.md tuning log).
-template <bool RAW, int NCH, int PFD, bool NT, int S0, typename ARGS>
+// LIST: the launch names its streams (nvx_kernels.h, nvx_part: a push-mode handle whose streams have come apart in
+// time).  A kernel of its own, so that the launches of every stream -- the roofline configuration -- run exactly the
+// code they ran before lists existed (with the list test inside it the headline kernel was 0.8 % slower: 20.50 against
+// 20.34 ms, same box, interleaved, profiles/r03).
+template <bool RAW, int NCH, int PFD, bool NT, int S0, typename ARGS, bool LIST = false>
 __device__ __forceinline__ void cascade_wave_main(ARGS a)
 {
     __shared__ CascadeLds<NCH> lds;
@@ -244,9 +248,16 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         if (u < n_full) { const int frame = u / a.n_streams; entry = u - frame * a.n_streams; tpart = 3 * frame; thirds = 3; }
         else { const int v = u - n_full, q = v / a.n_streams; entry = v - q * a.n_streams; tpart = 3 * a.split_from + q; thirds = 1; }
         const int part = tpart;                        // (position in the stream, in thirds)
-        // which stream: the launch's list of participants (nvx_kernels.h, nvx_part), or every stream in index order
-        int stream = entry, parity = a.parity;
-        if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); stream = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
+        // which stream: every stream in index order, all reading state[0] and writing state[1] -- or (LIST) the launch's
+        // list of participants (nvx_kernels.h, nvx_part), each with its own parity
+        int stream = entry;
+        const uint8_t *state_rd = a.state[0];
+        uint8_t *state_wr = a.state[1];
+        if (LIST) {
+            const unsigned long long e = nvx_load_const_u64(a.part + entry);      // { stream, parity }
+            stream = (int)(unsigned)e;
+            if (e >> 32) { state_rd = a.state[1]; state_wr = a.state[0]; }
+        }
         int *const done = a.done + entry;              // hand-over flag of this stream within the launch
         const unsigned mask = a.chain_masks[stream];
 
@@ -306,8 +317,8 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         // A stream's first unit of a launch reads the block the stream's previous launch left (state[parity]); every
         // unit writes the other one, and the host flips the stream's parity behind every launch it took part in -- so
         // a launch never reads and writes the same block through different units (the independent units run in any order).
-        double2 *st = (double2 *)((parity ? a.state[0] : a.state[1]) + (size_t)stream * NVX_CASCADE_STATE_BYTES);
-        const double2 *st_in = (part == 0) ? (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
+        double2 *st = (double2 *)(state_wr + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+        const double2 *st_in = (part == 0) ? (const double2 *)(state_rd + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start; the pre-roll starts
         // 576 = 0 mod 9 outputs earlier: same index); FIR3 outputs of the pre-roll are not written
         cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_THIRD_Y3, a.y3_cap,
@@ -410,9 +421,18 @@ __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void nvx_fir_cascade_cic3_1(nvx_cascade_args a) { cascade_wave_main<true, 1, 1, true, 3, const nvx_cascade_args &>(a); }
 __global__ __launch_bounds__(64) void nvx_fir_cascade_cic3_2(nvx_cascade_args a) { cascade_wave_main<true, 2, 1, true, 3, const nvx_cascade_args &>(a); }
 
-template <bool RAW, int NCH, int PFD, bool NT, int S0> struct CascadeKernel { static constexpr auto fn = nvx_fir_cascade<RAW, NCH, PFD, NT>; };
-template <> struct CascadeKernel<true, 1, 1, true, 3> { static constexpr auto fn = nvx_fir_cascade_cic3_1; };
-template <> struct CascadeKernel<true, 2, 1, true, 3> { static constexpr auto fn = nvx_fir_cascade_cic3_2; };
+// The same kernels for launches that name their streams (LIST; shipped configuration only: one pass of prefetch, nt loads).
+template <bool RAW, int NCH, int S0>
+__global__ __launch_bounds__(64) void nvx_fir_cascade_list(nvx_cascade_args a)
+{
+    if (RAW) cascade_wave_main<RAW, NCH, 1, true, S0, const nvx_cascade_args &, true>(a);
+    else cascade_wave_main<RAW, NCH, 1, true, S0, const nvx_cascade_args, true>(a);
+}
+
+template <bool RAW, int NCH, int PFD, bool NT, int S0, bool LIST = false> struct CascadeKernel { static constexpr auto fn = nvx_fir_cascade<RAW, NCH, PFD, NT>; };
+template <> struct CascadeKernel<true, 1, 1, true, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_1; };
+template <> struct CascadeKernel<true, 2, 1, true, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_2; };
+template <bool RAW, int NCH, int S0> struct CascadeKernel<RAW, NCH, 1, true, S0, true> { static constexpr auto fn = nvx_fir_cascade_list<RAW, NCH, S0>; };
 
 // ===========================================================================
 // launcher (C linkage, called from the host runtime)
@@ -421,7 +441,7 @@ template <> struct CascadeKernel<true, 2, 1, true, 3> { static constexpr auto fn
 // tuning switches for A/B runs (defaults are the shipped configuration; read once per process)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
-template <bool RAW, int NCH, int PFD, bool NT, int S0 = 1>
+template <bool RAW, int NCH, int PFD, bool NT, int S0 = 1, bool LIST = false>
 static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
 {
     // persistent grid: as many single-wave workgroups as the device of this launch holds at once (cached per device:
@@ -438,7 +458,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
         if (!cached) {
             int cus = 0, per_cu = 0;
             e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, CascadeKernel<RAW, NCH, PFD, NT, S0>::fn, 64, 0);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, CascadeKernel<RAW, NCH, PFD, NT, S0, LIST>::fn, 64, 0);
             if (e != hipSuccess) return e;
             const int cap = env_int("NVX_WAVES_PER_CU", 0);
             if (cap > 0 && cap < per_cu) per_cu = cap;
@@ -471,7 +491,7 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     // (NVX_DYNAMIC_PREROLL=0: it waits, as in round 1)
     static const int dynamic = env_int("NVX_DYNAMIC_PREROLL", 1);
     args.dynamic_preroll = dynamic != 0;
-    hipLaunchKernelGGL((CascadeKernel<RAW, NCH, PFD, NT, S0>::fn), dim3(grid), dim3(64), 0, s, args);
+    hipLaunchKernelGGL((CascadeKernel<RAW, NCH, PFD, NT, S0, LIST>::fn), dim3(grid), dim3(64), 0, s, args);
     return hipGetLastError();
 }
 
@@ -485,7 +505,13 @@ extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int
 #define NVX_CASE(R, C) ( \
         pfd == 2 ? (nt ? launch_cascade_as<R, C, 2, true>(a, s) : launch_cascade_as<R, C, 2, false>(a, s)) \
                  : (nt ? launch_cascade_as<R, C, 1, true>(a, s) : launch_cascade_as<R, C, 1, false>(a, s)))
-    // the third-order stage 0 exists in the shipped configuration only (one pass of prefetch, nt loads)
+    // launches that name their streams, and the third-order stage 0, exist in the shipped configuration only (one pass
+    // of prefetch, nt loads)
+    if (a->part) {
+        if (raw && a->stage0_order == 3) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 3, true>(a, s) : launch_cascade_as<true, 2, 1, true, 3, true>(a, s);
+        if (raw) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 1, true>(a, s) : launch_cascade_as<true, 2, 1, true, 1, true>(a, s);
+        return nch == 1 ? launch_cascade_as<false, 1, 1, true, 1, true>(a, s) : launch_cascade_as<false, 2, 1, true, 1, true>(a, s);
+    }
     if (raw && a->stage0_order == 3) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 3>(a, s) : launch_cascade_as<true, 2, 1, true, 3>(a, s);
     if (raw) return nch == 1 ? NVX_CASE(true, 1) : NVX_CASE(true, 2);
     return nch == 1 ? NVX_CASE(false, 1) : NVX_CASE(false, 2);

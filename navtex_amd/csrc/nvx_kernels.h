@@ -58,11 +58,11 @@ typedef struct {
     size_t first_sample;       /* first complex sample of this launch in every stream  */
     int n_frames;
     int n_streams;             /* streams taking part in this launch                   */
-    const nvx_part *part;      /* [n_streams], or NULL: streams 0 .. n_streams-1, parity `parity` */
-    int parity;
+    const nvx_part *part;      /* [n_streams], or NULL: streams 0 .. n_streams-1, all of parity 0 */
     const uint8_t *chain_masks;
-    uint8_t *state[2];         /* [all streams][NVX_CASCADE_STATE_BYTES] each: a stream's launch reads [its parity] (left by ITS */
-                               /* previous launch) and writes the other; hand-over inside the launch goes through the written one */
+    uint8_t *state[2];         /* [all streams][NVX_CASCADE_STATE_BYTES] each: a stream of parity p reads [p] (left by ITS previous */
+                               /* launch) and writes [p ^ 1]; hand-over inside the launch goes through the written one.  Without a  */
+                               /* list the host passes the block to read as [0] and the one to write as [1]                        */
     double2 *y3;               /* [all streams*2][y3_cap]                              */
     size_t y3_cap, y3_base;
     int *queue;                /* NVX_CASCADE_CTRL_INTS control ints followed by ...   */
@@ -129,12 +129,12 @@ typedef struct {
     const uint32_t *raw;       /* [n_wide][pitch] packed IQ at 2.016 MS/s                                    */
     size_t pitch, first_sample;
     int n_wide, n_frames;      /* n_wide: wideband streams taking part in this launch                         */
-    const nvx_part *part;      /* [n_wide], or NULL: streams 0 .. n_wide-1 with parity `parity`               */
-    int parity;
+    const nvx_part *part;      /* [n_wide], or NULL: streams 0 .. n_wide-1, all of parity 0                   */
     const uint8_t *chain_masks;/* [8 * all wideband streams]                                                  */
     uint8_t *state[2];         /* cascade state blocks of the decoded streams, as nvx_cascade_args            */
     uint32_t *hist[2];         /* [all wideband streams][40] raw words in front of the launch: read [parity], */
-                               /* written [parity ^ 1] (hand-over inside this launch and to the next one)     */
+                               /* written [parity ^ 1] (hand-over inside this launch and to the next one);    */
+                               /* without a list the host passes (read, write) as ([0], [1]), like state      */
     double2 *y3; size_t y3_cap, y3_base;
     int *queue, *status, *done;/* as nvx_cascade_args; done[n_wide]                                          */
     int independent;           /* set by the launcher: units pre-roll instead of waiting for their predecessor */

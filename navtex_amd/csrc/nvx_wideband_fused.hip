@@ -70,7 +70,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         if (u >= n_units) break;
         const int part = u / a.n_wide;                  // frame of the launch
         const int entry = u - part * a.n_wide;          // position in the launch's list of participants (nvx_kernels.h, nvx_part)
-        int w = entry, parity = a.parity;               // wideband stream, and which of its state blocks it reads
+        int w = entry, parity = 0;                      // wideband stream, and which of its state blocks it reads
         if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); w = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
         int *const done = a.done + entry;
         const int s = NVX_WB_SUBBANDS_K * w + wave;     // decoded 252 kS/s stream of this wave

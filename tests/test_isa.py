@@ -49,7 +49,9 @@ def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
     assert "s_barrier" not in main                                     # single-wave workgroups: compiler fences only
 
 
-@pytest.mark.parametrize("inst", ["ILb1ELi1ELi1ELb1", "ILb1ELi2ELi1ELb1", "ILb0ELi1ELi1ELb1", "ILb0ELi2ELi1ELb1", "_cic3_1", "_cic3_2"])
+@pytest.mark.parametrize("inst", ["ILb1ELi1ELi1ELb1", "ILb1ELi2ELi1ELb1", "ILb0ELi1ELi1ELb1", "ILb0ELi2ELi1ELb1", "_cic3_1", "_cic3_2",
+                                  # r3: the kernels of launches that name their streams (participant list read with ONE scalar load)
+                                  "_listILb1ELi1ELi1E", "_listILb1ELi2ELi1E", "_listILb0ELi1ELi1E", "_listILb0ELi2ELi1E", "_listILb1ELi1ELi3E"])
 def test_unit_hand_over_is_fence_free_and_device_coherent(isa, inst):
     """The hand-over of filter state between the units of a stream (nvx_cascade.hip, state_load / state_store / done[])
     rests on per-instruction device coherence instead of cache-wide fences.  What the hardware needs for that
@@ -71,6 +73,8 @@ def test_unit_hand_over_is_fence_free_and_device_coherent(isa, inst):
     assert sum(l.endswith(" sc1") for l in st8) >= n_state
     assert sum(not l.endswith(" sc1") for l in st8) <= 2 * n_chains          # the 900 S/s output, plain stores
     assert any(re.match(r"global_load_dword .* sc1$", l) for l in lines)    # done[] poll
+    if "_list" in inst:                                                     # the list entry: a scalar load, not one per lane
+        assert not any(l.startswith("global_load_dwordx2") and not l.endswith(" sc1") for l in lines)
     drains = [i for i, l in enumerate(lines) if l == "s_waitcnt vmcnt(0)"]
     assert len(drains) >= 2
     flag = max(i for i, l in enumerate(lines) if l.startswith("global_store_dword "))
