@@ -55,6 +55,9 @@ template <int NCH> struct GeoSizes {
     static constexpr int U_ENTRIES = ((46 + Geo<NCH>::U_PEND_MAX) + 7) / 8 * 8;
     static constexpr int Y2_ENTRIES = ((70 + Geo<NCH>::Y2_RUN) + 7) / 8 * 8;
 };
+// FIR3 takes its batch the moment it is complete and leaves nothing pending (the slide behind it keeps the 70 history
+// entries only): a batch must be a whole number of FIR2 runs
+static_assert(Geo<1>::Y2_RUN % Geo<1>::Y2_PER_RUN == 0 && Geo<2>::Y2_RUN % Geo<2>::Y2_PER_RUN == 0, "NVX_Y2_RUN: a whole number of FIR2 runs (160)");
 static_assert(Geo<1>::U_RUN % 32 == 0 && Geo<2>::U_RUN % 16 == 0 && 46 + Geo<1>::U_LEFT_MAX <= 128 && 46 + Geo<2>::U_LEFT_MAX <= 128, "slide covers two rows of 64");
 
 template <int NCH>
@@ -83,7 +86,9 @@ __device__ __forceinline__ double dpp_swap_pairs_f64(double v)
 #ifndef NVX_F1_AHEAD
 #define NVX_F1_AHEAD 3                    /* groups in flight ahead of the arithmetic */
 #endif
+#ifndef NVX_F23_AHEAD
 #define NVX_F23_AHEAD 12                  /* FIR2 / FIR3: taps read ahead */
+#endif
 /* FIR2 / FIR3 tap i: a plain literal.  The compiler creates all 118 at kernel entry, parks most of them in VGPR lanes
  * (70 "SGPR spills") and fetches a tap back with two v_readlane in front of its multiply.  -DNVX_TAPS_INPLACE creates every
  * tap where it is used instead (two s_mov_b32, nvx_device.h): no spill, no v_readlane, 212 vector instructions fewer in

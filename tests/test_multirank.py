@@ -214,3 +214,21 @@ def test_plain_bench_gpus_2_runs_two_ranks_on_one_gpu():
     assert r["world_size_seen"] == 2 and r["backend"] == "gloo" and r["parity_streams_checked_per_rank"] == [32, 32]
     assert len(r["ms_per_step_per_rank"]) == 2 and r["ms_per_step_min"] <= r["ms_per_step_max"] <= rec["ms_per_step"] * 1.5
     assert r["device_per_rank"] == [0, 0]
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_multi_gpu_run_on_one_gpu():
+    """The N > 1 path talks to RCCL (torch's "nccl" backend) for its barrier, MAX / MIN / SUM and the per-rank gathers, on
+    device tensors.  No multi-GPU box has run it yet (SCALE_r01 / r02: skipped), so rehearse exactly those calls with a
+    process group of ONE rank on the one GPU there is: NVX_BENCH_FORCE_DIST=1 under the launcher the driver uses."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(NVX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--streams", "96", "--frames", "6",
+                          "--steps", "2", "--warmup", "1", "--no-cpu", "--no-legs", "--no-stage0-extra", "--verify", "32"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["parity"] is True
+    assert rec["ranks"]["backend"] == "rccl" and rec["ranks"]["world_size_seen"] == 1 and rec["ranks"]["parity_streams_checked_per_rank"] == [32]
