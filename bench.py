@@ -720,6 +720,9 @@ def main():
                     traffic_source = "profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured by this run)"
             except Exception:
                 traffic = None
+        if traffic is None:
+            traffic_source = (f"null: profiles/hbm_traffic.json holds the PMC record of 4096 x 12 with the first-order stage 0 only, "
+                              f"not of {S} x {F}, stage0 order {order} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: tools/gpu_scripts/gpu_r03_final.sh)")
         roofline = {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>" if order == 1 else "nvx_fir_cascade_cic3_1", "achieved": round(achieved, 1) if achieved else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_step,

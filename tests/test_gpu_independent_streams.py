@@ -213,3 +213,61 @@ def test_wideband_streams_advance_independently(nv, oracle):
         p.flush()
         got = [p.bits(8 * w + k, c) for w in range(2) for k in range(8) for c in (0, 1)]
         assert got == want and all(len(b) > 50 for b in want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_randomized_ragged_streams(nv, oracle, seed):
+    """Random handles (stream count, chain masks, input rate, stage-0 order, max_frames) fed in random order with random
+    chunk sizes, streams going silent for a while (explicitly inactive, or simply not fed until another stream's staging
+    fills), a reset-free flush in the middle: every list kernel (252 kS/s and raw rate, one and two chains, both stage-0
+    forms) meets partial launches, per-stream parities and per-stream sample counts.  Every chain == the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    raw = bool(rng.integers(0, 2))
+    order = int(rng.choice([1, 3])) if raw else 1
+    S = int(rng.integers(2, 9))
+    F = int(rng.integers(6, 12))
+    maxf = int(rng.integers(1, 4))
+    masks = [int(rng.choice([1, 2, 3])) for _ in range(S)] if seed % 2 else [int(rng.choice([1, 2]))] * S      # odd seeds: NCH = 2 kernels
+    rate, frame = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)
+    iqs = []
+    for s in range(S):
+        carriers = []
+        for c, f in ((0, 14000), (1, -14000)):
+            if (masks[s] >> c) & 1:
+                h = signals.mix32(9000 * seed + 2 * s + c)
+                carriers.append(dict(freq_hz=f, bits=nv.sitor_encode(f"ZCZC R{chr(65 + s)}{seed}{c}\nRAGGED {s}\nNNNN\n", 10),
+                                     bit_offset=(h % (rate // 100)) | 1, phase0=signals.mix32(h), amplitude=6000))
+        iqs.append(nv.synth_host(nv.make_stream(carriers, seed=seed * 100 + s, noise_amp=1200), rate, F * frame))
+    with nv.Pipeline(n_streams=S, raw_rate=raw, chain_masks=masks, max_frames=maxf, push_mode=True, char_layer=False, stage0_order=order) as p:
+        pos = [0] * S
+        asleep = {}                                             # stream -> pushes (of others) until it wakes
+        flushed = False
+        while any(q < F * frame for q in pos):
+            for s in list(asleep):
+                asleep[s] -= 1
+                if asleep[s] <= 0: del asleep[s]
+            live = [s for s in range(S) if pos[s] < F * frame and s not in asleep]
+            if not live:
+                asleep.clear(); continue
+            s = int(rng.choice(live))
+            m = int(min(F * frame - pos[s], rng.integers(1, 2 * frame)))
+            p.push(s, iqs[s][pos[s]:pos[s] + m]); pos[s] += m
+            r = rng.random()
+            if r < 0.08 and len(asleep) < S - 1:                # a radio goes quiet: sometimes declared, sometimes just silent
+                z = int(rng.integers(0, S))
+                asleep[z] = int(rng.integers(3, 25))
+                if rng.random() < 0.5: p.set_active(z, False)
+            elif r < 0.11 and not flushed:
+                p.flush(); flushed = True
+        p.flush()
+        assert p.stream_stats(0)[2] >= 0
+        for s in range(S):
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
+            if raw:
+                ref.set_stage0(order); ref.push_raw(iqs[s])
+            else:
+                ref.push(iqs[s])
+            for c in range(2):
+                want = ref.bits(c) if (masks[s] >> c) & 1 else ""
+                assert p.bits(s, c) == want, f"seed {seed}: stream {s} chain {c} (raw {raw}, order {order}, masks {masks}, max_frames {maxf})"
+            assert p.stream_stats(s)[1] == F
