@@ -215,8 +215,7 @@ def test_wideband_streams_advance_independently(nv, oracle):
         assert got == want and all(len(b) > 50 for b in want)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
-def test_randomized_ragged_streams(nv, oracle, seed):
+def ragged_case(nv, oracle, seed):
     """Random handles (stream count, chain masks, input rate, stage-0 order, max_frames) fed in random order with random
     chunk sizes, streams going silent for a while (explicitly inactive, or simply not fed until another stream's staging
     fills), a reset-free flush in the middle: every list kernel (252 kS/s and raw rate, one and two chains, both stage-0
@@ -260,7 +259,7 @@ def test_randomized_ragged_streams(nv, oracle, seed):
             elif r < 0.11 and not flushed:
                 p.flush(); flushed = True
         p.flush()
-        assert p.stream_stats(0)[2] >= 0
+        partial = p.stream_stats(0)[2]
         for s in range(S):
             ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
             if raw:
@@ -271,3 +270,28 @@ def test_randomized_ragged_streams(nv, oracle, seed):
                 want = ref.bits(c) if (masks[s] >> c) & 1 else ""
                 assert p.bits(s, c) == want, f"seed {seed}: stream {s} chain {c} (raw {raw}, order {order}, masks {masks}, max_frames {maxf})"
             assert p.stream_stats(s)[1] == F
+    return dict(seed=seed, raw=raw, order=order, streams=S, frames=F, max_frames=maxf, two_chain_kernel=3 in masks, partial_launches=partial)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_randomized_ragged_streams(nv, oracle, seed):
+    info = ragged_case(nv, oracle, seed)
+    assert info["partial_launches"] > 0, info               # every case really had launches of only some streams
+
+
+def test_ragged_cases_cover_every_list_kernel(nv, oracle):
+    """The seeds above and a few more, by what they exercise: each of the six list kernels (252 kS/s and raw rate x one and
+    two chains, third-order stage 0 x one and two chains) must have met partial launches at least once."""
+    seen = set()
+    for seed in range(1, 40):
+        rng = np.random.default_rng(1000 + seed)            # the case's first draws, without running it
+        raw = bool(rng.integers(0, 2)); order = int(rng.choice([1, 3])) if raw else 1
+        kind = (raw, order, bool(seed % 2))
+        if kind in seen:
+            continue
+        info = ragged_case(nv, oracle, seed)
+        if info["partial_launches"] > 0:
+            seen.add((info["raw"], info["order"], info["two_chain_kernel"]))
+        if len(seen) == 6:
+            break
+    assert seen == {(False, 1, False), (False, 1, True), (True, 1, False), (True, 1, True), (True, 3, False), (True, 3, True)}, seen
