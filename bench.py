@@ -372,7 +372,7 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
         raw.free()
 
 
-def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_push=4, passes=6):
+def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_push=4, passes=6, pushers=4):
     """Streaming runs are reported separately: `n_streams` streams fed from HOST memory through nvx_push_iq ->
     pinned staging -> hipMemcpyAsync -> kernels -> bits, the loop that replaces receiver/capt_sched.c:484-528.  PCIe-bound by
     nature (4 B per sample); never `value`."""
@@ -387,10 +387,22 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
     # of the headline kernel's rocprofv3 statistics (they run nvx_fir_cascade<raw,2>)
     p = nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_mask=nv.CHAIN_518 | nv.CHAIN_490, max_frames=fpp, push_mode=True, char_layer=True, device=device)
 
-    def one_pass():
+    # one "capture thread" per group of streams, as a receiver with several radios has them: big pushes copy into the
+    # pinned staging without the handle's lock, so the threads fill their streams' staging side by side
+    import threading
+    n_thr = max(1, min(pushers, n_streams))
+
+    def feed(t):
         for c0 in range(0, n_per, chunk):
-            for s in range(n_streams):
+            for s in range(t, n_streams, n_thr):
                 p.push(s, host[s, c0:c0 + chunk])
+
+    def one_pass():
+        if n_thr == 1:
+            return feed(0)
+        ths = [threading.Thread(target=feed, args=(t,)) for t in range(n_thr)]
+        for th in ths: th.start()
+        for th in ths: th.join()
 
     one_pass(); p.flush()                                   # from reset state: the checked pass (also the warm-up)
     _secs, want = ob.bench(host, n_streams, n_per // 8, True, 1, ncpu, want_bits=True)
@@ -403,11 +415,11 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
     el = time.perf_counter() - t0
     p.close()
     n = passes * n_streams * n_per
-    return {"what": f"HOST-FED: {n_streams} streams x 2.016 MS/s pushed from host memory {fpp} frames at a time (nvx_push_iq -> pinned staging -> "
+    return {"what": f"HOST-FED: {n_streams} streams x 2.016 MS/s pushed from host memory by {n_thr} threads, {fpp} frames at a time (nvx_push_iq -> pinned staging -> "
                     f"hipMemcpyAsync -> kernels -> bits -> character layer), both chains of every stream decoded, {passes} passes over {n_fr} frames; PCIe-inclusive, never `value`",
             "value": round(n / el / 1e6, 1), "unit": "Msamples/s", "h2d_inclusive_gbs": round(4 * n / el / 1e9, 2),
             "x_real_time": round(n / el / nv.RATE_RAW, 1), "x_real_time_per_stream": round(n / el / nv.RATE_RAW / n_streams, 1),
-            "seconds": round(el, 3), "parity": ok, "parity_streams_checked": n_streams,
+            "seconds": round(el, 3), "pusher_threads": n_thr, "parity": ok, "parity_streams_checked": n_streams,
             "parity_note": "bits of the first pass (from reset state) == oracle on every stream; the timed passes repeat the same frames"}
 
 
@@ -808,7 +820,7 @@ def main():
             if rec.get("parity") is False:               # ... but wrong bits anywhere fail the run
                 print(f"PARITY FAILURE ({name} leg): GPU bits differ from the CPU oracle", file=sys.stderr)
                 parity = False; line["parity"] = False
-        run_leg("push_path", lambda: leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=min(64, S)))
+        run_leg("push_path", lambda: leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=min(64, S), pushers=min(4, ncpu)))
         buf.free()                                       # room for the 252 kS/s batch of the same size
         run_leg("variant_a", lambda: leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, not args.no_charlayer,
                                                    frames=8 * F if S * 8 * F * nv.FRAME_IN * 4 <= (140 << 30) else F))

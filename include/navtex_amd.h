@@ -198,7 +198,12 @@ NVX_API int  nvx_reset(nvx_handle *h);
  * frames) before that, the launch goes out with the streams that HAVE a frame,
  * each carrying its own filter / demodulator state -- a stalled or slower
  * radio never blocks the others, and rejoins later bit-exactly.  Returns
- * NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel form). */
+ * NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel form).
+ * Threads: any number of threads may push into one handle, ONE per stream at
+ * a time (a second pusher of the same stream waits).  Pushes of 128 KB and
+ * more copy into the pinned staging without the handle's lock, so the capture
+ * or replay threads of several radios fill their streams side by side; a
+ * launch first waits for the copies in flight to be committed.              */
 NVX_API int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq_interleaved, size_t n);
 NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n);
 /* Mark a stream of a push-mode handle inactive (0): launches no longer wait for it (a silent radio).  Pushing to it

@@ -208,6 +208,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->fill.assign(h->n_in, 0);
         h->cur.assign(h->n_in, 0);
         h->active.assign(h->n_in, 1);
+        h->writing.assign(h->n_in, 0);
     }
 #undef CR_TRY
     rc = nvx_reset(h);
@@ -220,7 +221,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
 extern "C" int nvx_reset(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
+    StagingQuiesce quiet(h, lk);                         // no push is copying into the staging sets while they are emptied
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));   // launches on a caller's stream included
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -136,9 +136,29 @@ struct nvx_handle {
     size_t stage_cap = 0;
     std::vector<size_t> fill;
     uint32_t *d_in = nullptr;
+    // Large pushes copy into the pinned staging WITHOUT the handle's lock, so that the capture threads of several radios
+    // (or replay threads) fill their streams' staging side by side: one thread's copy rate is ~30-40 GB/s, the PCIe link
+    // takes 50.  writing[s]: stream s has such a copy in flight (its fill / cur must not move: one writer per stream);
+    // writers: how many in all.  Whoever wants to move fill / cur (a launch out of the staging sets, flush, reset) raises
+    // quiesce, waits on wr_cv for writers == 0 (no new copy starts meanwhile) and lowers it again.
+    std::vector<uint8_t> writing;
+    int writers = 0, quiesce = 0;
+    std::condition_variable wr_cv;
 };
 
 struct SinkCtx { nvx_handle *h; int stream; int slot; };
+
+// Scope in which the staging sets may be rearranged: raised with the handle locked, waits (lock released meanwhile)
+// until the unlocked copies in flight have been committed; pushes start no new unlocked copy while one is up.
+struct StagingQuiesce {
+    nvx_handle *h; std::unique_lock<std::mutex> &lk;
+    StagingQuiesce(nvx_handle *h_, std::unique_lock<std::mutex> &lk_) : h(h_), lk(lk_)
+    {
+        h->quiesce++;
+        h->wr_cv.wait(lk, [&] { return h->writers == 0; });
+    }
+    ~StagingQuiesce() { h->quiesce--; h->wr_cv.notify_all(); }
+};
 
 // launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)
 // part / n_part: the input streams that take part, ascending (nullptr = every stream)

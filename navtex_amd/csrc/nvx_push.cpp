@@ -78,6 +78,9 @@ static int submit_locked(nvx_handle *h)
     return NVX_OK;
 }
 
+// pushes of at least this many bytes copy into the staging WITHOUT the handle's lock (nvx_handle.h: writing / writers)
+#define NVX_UNLOCKED_COPY_BYTES (128u << 10)
+
 // accepted (optional): how many of the n samples were staged -- all of them on NVX_OK, fewer on an error
 template <typename F>
 static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *accepted = nullptr)
@@ -85,15 +88,23 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (accepted) *accepted = 0;
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    h->wr_cv.wait(lk, [&] { return !h->writing[stream]; });       // a stream has one writer at a time
     if (n) h->active[stream] = 1;                    // a stream that delivers is (again) one the others wait for
     size_t done = 0;
+    // a launch out of the staging sets: with every unlocked copy committed, and only if `still` holds afterwards (another
+    // thread may have launched while this one waited)
+    auto launch_if = [&](auto still) -> int {
+        StagingQuiesce quiet(h, lk);
+        return still() ? submit_locked(h) : NVX_OK;
+    };
     while (done < n) {
+        if (h->quiesce) h->wr_cv.wait(lk, [&] { return h->quiesce == 0; });     // somebody is rearranging the staging sets
         size_t room = h->stage_cap - h->fill[stream];
         if (room == 0) {
             // this stream is max_frames + 1 frames ahead of a launch: go with the streams that have a frame
-            int rc = submit_locked(h);
+            int rc = launch_if([&] { return h->fill[stream] == h->stage_cap; });
             if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
             room = h->stage_cap - h->fill[stream];
             if (room == 0) {                         // only the two-kernel wideband form gets here
@@ -101,12 +112,27 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
                 if (accepted) *accepted = done;
                 return NVX_ERR_FULL;
             }
+            continue;                                // (the wait above released the lock: look again)
         }
-        size_t m = std::min(room, n - done);
-        copy_in(h->h_stage[h->cur[stream]] + (size_t)stream * h->stage_cap + h->fill[stream], done, m);
+        const size_t m = std::min(room, n - done);
+        uint32_t *dst = h->h_stage[h->cur[stream]] + (size_t)stream * h->stage_cap + h->fill[stream];
+        if (m * 4 >= NVX_UNLOCKED_COPY_BYTES) {
+            // the copy itself needs no lock: nobody moves this stream's fill / cur while writing[stream] is up
+            h->writing[stream] = 1; h->writers++;
+            lk.unlock();
+            copy_in(dst, done, m);
+            lk.lock();
+            h->writing[stream] = 0; h->writers--;
+            h->wr_cv.notify_all();
+        } else {
+            copy_in(dst, done, m);
+        }
         h->fill[stream] += m;
         done += m;
-        if (lockstep_ready(h)) { int rc = submit_locked(h); if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; } }
+        if (lockstep_ready(h)) {
+            int rc = launch_if([&] { return lockstep_ready(h); });
+            if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
+        }
     }
     if (accepted) *accepted = n;
     return NVX_OK;
@@ -134,9 +160,10 @@ extern "C" int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, con
 extern "C" int nvx_flush(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->cfg.push_mode) {
+        StagingQuiesce quiet(h, lk);                 // pushes in flight on other threads commit first
         // whatever is staged in whole frames goes out, stream by stream as far as each has got
         for (;;) {
             const uint64_t before = h->launched;
@@ -189,11 +216,14 @@ extern "C" int nvx_stream_set_active(nvx_handle *h, int stream, int active)
 {
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_set_active: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_stream_set_active: handle was not created with push_mode"); return NVX_ERR_STATE; }
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
     h->active[stream] = active ? 1 : 0;
     // the others may have been waiting for exactly this stream
-    if (!active && lockstep_ready(h)) return submit_locked(h);
+    if (!active && lockstep_ready(h)) {
+        StagingQuiesce quiet(h, lk);
+        if (lockstep_ready(h)) return submit_locked(h);
+    }
     return NVX_OK;
 }
 

@@ -295,3 +295,33 @@ def test_ragged_cases_cover_every_list_kernel(nv, oracle):
         if len(seen) == 6:
             break
     assert seen == {(False, 1, False), (False, 1, True), (True, 1, False), (True, 1, True), (True, 3, False), (True, 3, True)}, seen
+
+
+def test_several_threads_push_into_one_handle(nv, oracle):
+    """Capture / replay threads of several radios feeding ONE handle at once: pushes of 128 KB and more copy into the pinned
+    staging without the handle's lock (a launch first waits for the copies in flight to be committed).  Eight streams,
+    four threads with their own pace and push sizes, a flush from the main thread in between: every stream == the oracle."""
+    S, F, T = 8, 9, 4
+    iqs = [nv.synth_host(signals.stream_params(nv, 6400 + s, nv.RATE_RAW, n_phasing=12)[0], nv.RATE_RAW, F * nv.FRAME_RAW) for s in range(S)]
+    errors = []
+    with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=True) as p:
+        def feed(t):
+            rng = np.random.default_rng(t)
+            pos = {s: 0 for s in range(t, S, T)}
+            try:
+                while any(q < F * nv.FRAME_RAW for q in pos.values()):
+                    s = int(rng.choice([k for k, q in pos.items() if q < F * nv.FRAME_RAW]))
+                    m = int(min(F * nv.FRAME_RAW - pos[s], rng.choice([700, 5000, 40000, 300000, 900000])))
+                    p.push(s, iqs[s][pos[s]:pos[s] + m]); pos[s] += m
+                    if t == 3 and rng.random() < 0.1: time.sleep(0.002)          # one thread is slower than the rest
+            except Exception as e:                                      # noqa: BLE001 -- reported by the main thread
+                errors.append(repr(e))
+        threads = [threading.Thread(target=feed, args=(t,)) for t in range(T)]
+        for th in threads: th.start()
+        time.sleep(0.01); p.flush()
+        for th in threads: th.join()
+        p.flush()
+        assert not errors, errors
+        for s in range(S):
+            assert p.bits(s, 0) == _oracle_bits(oracle, iqs[s], True)[0] and len(p.bits(s, 0)) > 200
+            assert p.stream_stats(s)[1] == F

@@ -69,3 +69,18 @@ def test_host_pool_is_clean_under_tsan(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "tsan pool ok" in out.stdout
+
+
+def test_push_path_is_clean_under_tsan(tmp_path):
+    """ThreadSanitizer over the host-input path (nvx_push.cpp): six pusher threads (callback-sized and replay-sized pushes,
+    the big ones copying into the staging WITHOUT the handle's lock), a slow stream, a stream declared silent, a thread
+    flushing; HIP and the launch are stand-ins that record what reached the "device".  No race; every stream's samples
+    arrive exactly once and in order; partial launches really happened (tests/harness/tsan_push.cpp)."""
+    exe = tmp_path / "tsan_push"
+    csrc = ROOT / "navtex_amd" / "csrc"
+    subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    f"-I{ROOT / 'include'}", f"-I{csrc}", str(ROOT / "tests" / "harness" / "tsan_push.cpp"),
+                    str(csrc / "nvx_push.cpp"), "-x", "c", str(csrc / "nvx_wav.c"), "-o", str(exe), "-lpthread"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env={"TSAN_OPTIONS": "halt_on_error=1", "PATH": "/usr/bin:/bin"})
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "tsan push ok" in out.stdout

@@ -24,6 +24,29 @@ def run(n_streams, raw, frames_per_push, pushes):
     n = n_streams * pushes * block.shape[0]
     print(f"streams {n_streams:4d} raw {int(raw)} frames/push {frames_per_push}: {n/dt/1e6:9.1f} Msamples/s  {4*n/dt/1e9:6.2f} GB/s host->device inclusive", flush=True)
 
+def run_threads(n_streams, n_threads, frames_per_push, pushes):
+    """ONE handle fed by several threads, each owning a share of the streams: big pushes copy into the pinned staging
+    without the handle's lock (nvx_push.cpp), so the threads' copies overlap."""
+    import threading
+    st, _ = signals.stream_params(nv, 0, nv.RATE_RAW)
+    block = nv.synth_host(st, nv.RATE_RAW, frames_per_push * nv.FRAME_RAW)
+    with nv.Pipeline(n_streams=n_streams, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=frames_per_push, push_mode=True, char_layer=True) as p:
+        def feed(t, rounds):
+            for _ in range(rounds):
+                for s in range(t, n_streams, n_threads): p.push(s, block)
+        for t in range(n_threads): feed(t, 1)
+        p.flush()
+        threads = [threading.Thread(target=feed, args=(t, pushes)) for t in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in threads: t.start()
+        for t in threads: t.join()
+        p.flush()
+        dt = time.perf_counter() - t0
+    n = n_streams * pushes * block.shape[0]
+    print(f"one handle, {n_streams} streams, {n_threads} pusher thread(s), {frames_per_push} frames per push: "
+          f"{n/dt/1e6:9.1f} Msamples/s  {4*n/dt/1e9:6.2f} GB/s host->device inclusive", flush=True)
+
+
 def run_group(n_members, streams_per_member, frames_per_push, pushes):
     """One capture thread per member of a group, each pushing into its own member's streams (ctypes drops the GIL inside
     nvx_group_push_iq; the group holds no lock around it): the aggregate host-fed rate against one member alone."""
@@ -51,6 +74,10 @@ def run_group(n_members, streams_per_member, frames_per_push, pushes):
 
 
 if __name__ == "__main__":
+    if "--threads" in sys.argv:
+        for t in (1, 2, 4, 8):
+            run_threads(64, t, 2, 6)
+        sys.exit(0)
     if "--group" in sys.argv:
         one = run_group(1, 32, 2, 6)
         two = run_group(2, 32, 2, 6)
