@@ -96,6 +96,28 @@ def test_capture_loop_program_links_and_decodes(nv, tmp_path):
     assert sorted(got) == sorted(rec["messages"])
 
 
+def test_poll_takes_in_finished_work_without_waiting(nv, oracle):
+    """nvx_poll: results of launches that have finished reach the host (bits, messages) without a fetch, a flush or a
+    further launch; a poll right behind a launch returns at once whether or not the GPU is done."""
+    import time
+    import signals
+    st, _ = signals.stream_params(nv, 4300, nv.RATE_IN)
+    n_frames = 75
+    iq = nv.synth_host(st, nv.RATE_IN, n_frames * nv.FRAME_IN)
+    buf = nv.DeviceBuffer(iq.nbytes); buf.upload(iq)
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=n_frames) as p:
+        p.process_resident(buf, n_frames * nv.FRAME_IN, 0, n_frames)
+        t0 = time.perf_counter(); p.poll(); dt = time.perf_counter() - t0
+        assert dt < 0.05                                    # never waits
+        deadline = time.time() + 5.0
+        while p.bit_count(0, 0) == 0 and time.time() < deadline:
+            time.sleep(0.01); p.poll()
+        ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(iq)
+        assert p.bits(0, 0) == ref.bits(0) and len(p.messages) == 1          # all of it, and the message, with no fetch
+        p.poll()                                            # nothing in flight: a no-op
+    buf.free()
+
+
 def test_messages_reach_add_message_without_a_flush(nv, tmp_path):
     """An unmodified capt_sched.c never calls nvx_shim_flush: the same program, ending WITHOUT the
     flush, still sees every message of the frames that were launched -- the singleton's housekeeping thread takes in
