@@ -219,10 +219,12 @@ extern "C" int nvx_stream_set_active(nvx_handle *h, int stream, int active)
     std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
     h->active[stream] = active ? 1 : 0;
-    // the others may have been waiting for exactly this stream
-    if (!active && lockstep_ready(h)) {
+    // the others may have been waiting for exactly this stream; and when the LAST active stream goes silent, whole frames
+    // that were waiting for company go out now rather than when a radio comes back
+    auto due = [&] { return lockstep_ready(h) || std::none_of(h->active.begin(), h->active.end(), [](uint8_t a) { return a != 0; }); };
+    if (!active && due()) {
         StagingQuiesce quiet(h, lk);
-        if (lockstep_ready(h)) return submit_locked(h);
+        if (due()) return submit_locked(h);
     }
     return NVX_OK;
 }

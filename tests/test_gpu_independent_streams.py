@@ -83,6 +83,13 @@ def test_inactive_stream_is_not_waited_for(nv, oracle):
         p.flush()
         for s in range(2):
             assert p.bits(s, 0) == _oracle_bits(oracle, iqs[s], False)[0]
+    # when the LAST active stream goes silent, whole frames that were waiting for company go out at once
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=4, push_mode=True, char_layer=False) as p:
+        p.push(0, iqs[0][:nv.FRAME_IN + 500])                           # a frame and a bit, waiting for stream 1
+        p.set_active(0, False)                                          # its own radio dies first: still waiting ...
+        assert p.stream_stats(0)[1] == 0
+        p.set_active(1, False)                                          # ... nobody left to wait for
+        assert p.stream_stats(0)[1] == 1
 
 
 def test_resident_launches_after_divergence(nv, oracle):
@@ -325,3 +332,47 @@ def test_several_threads_push_into_one_handle(nv, oracle):
         for s in range(S):
             assert p.bits(s, 0) == _oracle_bits(oracle, iqs[s], True)[0] and len(p.bits(s, 0)) > 200
             assert p.stream_stats(s)[1] == F
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_randomized_ragged_wideband_inputs(nv, oracle, seed):
+    """The fused wideband kernel with participant lists, randomised: two or three 2.016 MS/s inputs (16 carriers each) fed
+    in random order with random chunk sizes and silent spells; sub-band filter state and the channeliser's 40-sample halo
+    follow each input's own parity.  All carriers == the restatement chain."""
+    import os
+    if os.environ.get("NVX_WB_FUSED", "1") == "0":
+        pytest.skip("the two-kernel A/B form launches all streams together")
+    rng = np.random.default_rng(500 + seed)
+    W, F, maxf = int(rng.integers(2, 4)), int(rng.integers(3, 6)), int(rng.integers(1, 3))
+    n = F * nv.FRAME_RAW
+    raws = []
+    for w in range(W):
+        carriers = []
+        for k in range(8):
+            centre = k * 252000 if k < 4 else (k - 8) * 252000
+            for c, off in ((0, 14000), (1, -14000)):
+                cid = 1000 * seed + 16 * w + 2 * k + c
+                carriers.append(dict(freq_hz=centre + off, bits=nv.sitor_encode(signals.stream_text(8000 + cid), 8),
+                                     bit_offset=(signals.mix32(cid) % 20160) | 1, phase0=signals.mix32(cid ^ 0x1234), amplitude=1600))
+        raws.append(nv.synth_host(nv.make_stream(carriers, seed=seed * 10 + w, noise_amp=500), nv.RATE_RAW, n))
+    _secs, want = oracle.bench_wide(np.stack(raws), W, n // 8, 4, want_bits=True)
+    with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=maxf, push_mode=True, char_layer=False) as p:
+        pos = [0] * W
+        quiet = {}
+        while any(q < n for q in pos):
+            for w in list(quiet):
+                quiet[w] -= 1
+                if quiet[w] <= 0: del quiet[w]
+            live = [w for w in range(W) if pos[w] < n and w not in quiet]
+            if not live:
+                quiet.clear(); continue
+            w = int(rng.choice(live))
+            m = int(min(n - pos[w], rng.integers(1, 2 * nv.FRAME_RAW)))
+            p.push(w, raws[w][pos[w]:pos[w] + m]); pos[w] += m
+            if rng.random() < 0.15 and len(quiet) < W - 1:
+                z = int(rng.integers(0, W)); quiet[z] = int(rng.integers(2, 8))
+                if rng.random() < 0.5: p.set_active(z, False)
+        p.flush()
+        got = [p.bits(8 * w + k, c) for w in range(W) for k in range(8) for c in (0, 1)]
+        assert got == want and all(len(b) > 30 for b in want)
+        assert p.stream_stats(0)[2] > 0, "the case must have had launches of only some inputs"
