@@ -343,7 +343,7 @@ def test_randomized_ragged_wideband_inputs(nv, oracle, seed):
     if os.environ.get("NVX_WB_FUSED", "1") == "0":
         pytest.skip("the two-kernel A/B form launches all streams together")
     rng = np.random.default_rng(500 + seed)
-    W, F, maxf = int(rng.integers(2, 4)), int(rng.integers(3, 6)), int(rng.integers(1, 3))
+    W, F, maxf = int(rng.integers(2, 4)), int(rng.integers(4, 7)), int(rng.integers(1, 3))
     n = F * nv.FRAME_RAW
     raws = []
     for w in range(W):
