@@ -65,8 +65,19 @@ struct CascadeLds {
     double2 X[X_ENTRIES];
     double2 U[NCH][GeoSizes<NCH>::U_ENTRIES];
     double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES];
+#ifndef NVX_MIX_GLOBAL
     double2 mix[2][2 * NVX_MIX_N];      // [sign of the cross term][two periods of (cos, -+sin)]
+#endif
 };
+
+#ifdef NVX_MIX_GLOBAL
+// A/B build: the mixer table in device memory instead of LDS (576 B less per wave: 13 312 B, 12 waves per CU instead of
+// 11); one 16-byte load per lane per pass, issued a pass ahead of its use.
+#define NVX_MIXE(j, S) { NVX_MIX_CR[(j) % NVX_MIX_N], S NVX_MIX_CI[(j) % NVX_MIX_N] }
+#define NVX_MIXROW(S) { NVX_MIXE(0, S), NVX_MIXE(1, S), NVX_MIXE(2, S), NVX_MIXE(3, S), NVX_MIXE(4, S), NVX_MIXE(5, S), NVX_MIXE(6, S), NVX_MIXE(7, S), NVX_MIXE(8, S), \
+                      NVX_MIXE(9, S), NVX_MIXE(10, S), NVX_MIXE(11, S), NVX_MIXE(12, S), NVX_MIXE(13, S), NVX_MIXE(14, S), NVX_MIXE(15, S), NVX_MIXE(16, S), NVX_MIXE(17, S) }
+static __device__ const double2 nvx_mix_global[2][2 * NVX_MIX_N] = { NVX_MIXROW(+), NVX_MIXROW(-) };
+#endif
 
 __device__ __forceinline__ int dpp_swap_pairs(int v)
 {
@@ -148,7 +159,11 @@ struct CascadeWave {
     CascadeLds<NCH> *lds;
     int lane, half, comp;
     const lds_vdouble *xrv;              // FIR1 read base: sample 8*half + t is component comp of X[(t & 7) * XS + XH + half + floor(t / 8)]
+#ifdef NVX_MIX_GLOBAL
+    const nvx_d2 *mixrow;                // this lane's row of the mixer table in device memory (set per unit)
+#else
     const lds_vd2 *mixrow;               // this lane's row of the mixer table (set per unit)
+#endif
     int lane_mod9;
     double h1v[NVX_T1];
     // per unit
@@ -165,6 +180,7 @@ struct CascadeWave {
         lds = l; lane = lane_; half = lane >> 1; comp = lane & 1;
         xrv = (const lds_vdouble *)((const double *)&lds->X[XH + half] + comp);
         lane_mod9 = (2 * half) % 9;
+#ifndef NVX_MIX_GLOBAL
         if (lane < 4 * NVX_MIX_N) {
             // constant-index selects keep the tables out of scratch
             const int j9 = lane % NVX_MIX_N;
@@ -174,6 +190,7 @@ struct CascadeWave {
             lds->mix[0][lane % (2 * NVX_MIX_N)] = double2{ cr, ci };      // both copies are written by two lanes each: same value
             lds->mix[1][lane % (2 * NVX_MIX_N)] = double2{ cr, -ci };
         }
+#endif
 #pragma unroll
         for (int i = 0; i < NVX_T1; i++)
             if (NVX_H1_FIRST.first[i] == i) { h1v[i] = NVX_H1[i]; asm volatile("" : "+v"(h1v[i])); }
@@ -186,7 +203,11 @@ struct CascadeWave {
         chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
         // mixer table row of this lane: its cross term carries the sign of the 518 chain (I lanes negated) -- or, when the
         // unit's only chain is the 490 one, of that chain (Q lanes negated); see step 4
+#ifdef NVX_MIX_GLOBAL
+        mixrow = (const nvx_d2 *)&nvx_mix_global[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
+#else
         mixrow = (const lds_vd2 *)&lds->mix[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
+#endif
         y3 = y3_; y3_row0 = row0; y3_cap = cap;
         mixbase = mixbase0; n_u = n_u0; n_y2 = n_y20; n3_done = 0; emit = emit0;
         mix_next = mixrow[mixbase];      // (behind init()'s table writes in this wave's LDS queue)
