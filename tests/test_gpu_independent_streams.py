@@ -4,6 +4,7 @@ receiver/fir2cpp.C:74-83) -- so a stream that stalls (an unplugged radio: receiv
 sdrplay_api_DeviceRemoved) or runs slow must not hold the others, and must rejoin bit-exactly from its own carried
 state.  Launches then cover a LIST of streams, each with its own state-block parity and sample count."""
 import ctypes as C
+from pathlib import Path
 import threading
 import time
 
@@ -376,3 +377,20 @@ def test_randomized_ragged_wideband_inputs(nv, oracle, seed):
         got = [p.bits(8 * w + k, c) for w in range(W) for k in range(8) for c in (0, 1)]
         assert got == want and all(len(b) > 30 for b in want)
         assert p.stream_stats(0)[2] > 0, "the case must have had launches of only some inputs"
+
+
+def test_ragged_cases_with_the_hand_over_forms_forced(nv, tmp_path):
+    """The ragged cases run few streams, so their launches use independent units.  Launches of thousands of streams that
+    name their streams hand filter state from unit to unit instead (done[] indexed by list position, state blocks by
+    stream and parity): force that form -- with and without the dynamic pre-roll -- in a subprocess and run cases that
+    between them cover all six list kernels."""
+    import subprocess, sys, os
+    root = str(Path(__file__).resolve().parent.parent)
+    for env in (dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="1"), dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="0"), dict(NVX_INDEPENDENT="1")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_scripts", "sweep_ragged.py"), "1", "20"],
+                             capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, (env, out.stdout[-1500:], out.stderr[-1500:])
+        last = out.stdout.strip().splitlines()[-1]
+        assert last.startswith("20 cases identical to the oracle"), last
+        kinds = last[last.index("{"):]
+        assert kinds.count("(") == 6, (env, last)                 # all six (rate, stage-0 order, chains) list kernels were met
