@@ -77,7 +77,7 @@ static void free_handle(nvx_handle *h)
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
     if (h->launch_done) hipEventDestroy(h->launch_done);
     hipFree(h->d_ties); if (h->h_ties) hipHostFree(h->h_ties);
-    hipFree(h->d_dd); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
+    hipFree(h->d_dd[0]); hipFree(h->d_dd[1]); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
     if (h->h_status) hipHostFree(h->h_status);
     for (auto &r : h->res) {
         hipFree(r.d_bits); hipFree(r.d_nbits);
@@ -167,7 +167,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_cstate[i], (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
-    CR_TRY(hipMalloc(&h->d_dd, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
+    for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_dd[i], (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
     CR_TRY(hipMalloc(&h->d_fsm_tab, NVX_FSM_TABLE_ALLOC * sizeof(uint32_t)));
     CR_TRY(hipMemcpy(h->d_fsm_tab, nvx_fsm_table_host(), NVX_FSM_TABLE_ALLOC * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -242,7 +242,7 @@ extern "C" int nvx_reset(nvx_handle *h)
         h->wide_launches = 0;
     }
     for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_cstate[i], 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_dd, 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_dd[i], 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
     std::vector<int> ints((size_t)NVX_DEMOD_INTS * h->n_slots, 0);
     for (int i = 0; i < h->n_slots; i++) {
@@ -371,7 +371,8 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
     da.g0 = h->g0s[0]; da.part = d_list; da.n_part = r.n_part; da.per_part = per_part;
-    da.dstate = h->d_dd; da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
+    da.dstate[0] = h->d_dd[p0]; da.dstate[1] = h->d_dd[p0 ^ 1];     // (read, write) without a list; [0], [1] with one
+    da.state_i = h->d_di; da.fsm_table = h->d_fsm_tab; da.words = h->d_words;
     da.bits = r.d_bits; da.bits_cap = h->bits_cap; da.nbits = r.d_nbits; da.dphi = h->d_dphi; da.ties = h->d_ties;
 
     // cascade on `st`: it may not overwrite y3[yb] before the demodulator of two launches ago has read it

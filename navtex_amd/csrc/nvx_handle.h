@@ -94,7 +94,8 @@ struct nvx_handle {
     uint8_t *d_masks = nullptr, *d_active = nullptr;
     uint8_t *d_cstate[2] = { nullptr, nullptr };   // cascade state blocks: launch k reads [k & 1], writes [(k + 1) & 1]
     double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
-    double *d_dd = nullptr, *d_dphi = nullptr; int *d_di = nullptr;
+    double *d_dd[2] = { nullptr, nullptr };   // demodulator state blocks: a chain reads [its stream's parity], writes the other
+    double *d_dphi = nullptr; int *d_di = nullptr;
     uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
     unsigned short *d_words = nullptr;
     nvx_tie_stats *d_ties = nullptr;   // arg-max margin statistics, cumulative since create / reset

@@ -96,7 +96,8 @@ typedef struct {
     const nvx_part *part;      /* participating streams of this launch, or NULL = all  */
     int n_part;                /* entries of part                                      */
     int per_part;              /* decoded streams per entry: 8 on a wideband handle (stream 8 * w + k), else 1 */
-    double *dstate;            /* [n_slots][NVX_DEMOD_DOUBLES]                         */
+    double *dstate[2];         /* [n_slots][NVX_DEMOD_DOUBLES] each: a chain of parity p reads [p] and writes [p ^ 1], as the    */
+                               /* cascade state; without a list the host passes (read, write) as ([0], [1])                      */
     int *state_i;              /* [field][n_slots]                                     */
     const uint32_t *fsm_table; /* NVX_FSM_TABLE_ALLOC entries (nvx_fsm.h), 16-byte aligned */
     unsigned short *words;     /* [n_slots][y3_cap/9] per-bit-period hand-over, front -> fsm (rows 16-byte aligned) */
