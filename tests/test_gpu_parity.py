@@ -451,3 +451,44 @@ def test_launches_on_different_streams_stay_ordered(nv, oracle):
                 assert p.bits(s, 0) == ref.bits(0), f"round {rep} stream {s}"
     nv.lib.nvx_stream_destroy(0, sa); nv.lib.nvx_stream_destroy(0, sb)
     buf.free()
+
+
+def test_demodulator_front_forms_agree_bit_for_bit(nv, tmp_path):
+    """The demodulator's front has two forms (r3): one workgroup per chain walking the tiles of a launch (many chains), or
+    one workgroup per tile from the third tile on, each rebuilding its 577-sample look-back (few chains, long launches;
+    chosen automatically).  Forced either way in a subprocess: delta-phi, bits and messages of launches of 4 + 25 + 9 + 1
+    frames (one to six tiles, carried state in between) are identical, and so are the tie statistics."""
+    import hashlib, subprocess, sys, os
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv, signals
+h = hashlib.sha256()
+masks = [1, 3, 2]
+streams = [signals.stream_params(nv, 900 + s, nv.RATE_IN, n_phasing=14)[0] for s in range(3)]
+F = 39
+buf = nv.DeviceBuffer(3 * F * nv.FRAME_IN * 4)
+nv.synth_device(streams, nv.RATE_IN, F * nv.FRAME_IN, buf, F * nv.FRAME_IN)
+with nv.Pipeline(n_streams=3, raw_rate=False, chain_masks=masks, max_frames=25) as p:
+    p.enable_debug(True)
+    f0 = 0
+    for k in (4, 25, 9, 1):
+        p.process_resident(buf, F * nv.FRAME_IN, f0, k); f0 += k
+        p.fetch()
+        for s in range(3):
+            for c in range(2):
+                if (masks[s] >> c) & 1: h.update(p.debug_dphi(s, c)[: k * nv.FRAME_Y3].tobytes())
+    for s in range(3):
+        for c in range(2): h.update(p.bits(s, c).encode())
+    h.update(repr(sorted(p.messages)).encode()); h.update(repr(p.tie_stats()).encode())
+    nbits = sum(len(p.bits(s, c)) for s in range(3) for c in range(2))
+print(h.hexdigest(), nbits, len(p.messages))
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    outs = []
+    for force in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=dict(os.environ, NVX_DEMOD_TILES=force))
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.strip().splitlines()[-1].split())
+    assert outs[0] == outs[1] and int(outs[0][1]) > 4000 and int(outs[0][2]) >= 3, outs
