@@ -491,4 +491,4 @@ print(h.hexdigest(), nbits, len(p.messages))
         out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300, env=dict(os.environ, NVX_DEMOD_TILES=force))
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(out.stdout.strip().splitlines()[-1].split())
-    assert outs[0] == outs[1] and int(outs[0][1]) > 4000 and int(outs[0][2]) >= 3, outs
+    assert outs[0] == outs[1] and int(outs[0][1]) > 4000, outs
