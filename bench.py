@@ -612,6 +612,11 @@ def main():
     place = place_rank(device, local_world, local)
 
     import torch
+    # Importing torch leaves millions of long-lived Python objects behind; a full garbage collection then takes ~40 ms, and
+    # the message callbacks of the timed loop (tuples, strings) are what triggers one (seen as a 42 ms step every ~30
+    # steps at 64 streams x 62 frames).  Park what exists now in the permanent generation: collections stay cheap.
+    import gc
+    gc.collect(); gc.freeze()
     dist = None
     # NVX_BENCH_FORCE_DIST=1: form the process group even for one rank (a one-GPU rehearsal of the RCCL calls the
     # multi-GPU run makes: init, barrier, all_reduce, all_gather on device tensors)

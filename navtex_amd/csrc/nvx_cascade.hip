@@ -476,17 +476,23 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     // get no unit in the last round idle for a third of a frame instead of a whole one (4096 x 12: 4.1 % of all wave
     // time was that idle tail).  NVX_TAIL_SPLIT=0: whole frames only; =n: the last n frames in thirds.
     nvx_cascade_args args = *a;
-    static const int tail_split = env_int("NVX_TAIL_SPLIT", -1);
-    int split_frames = tail_split >= 0 ? tail_split : ((long long)a->n_streams * a->n_frames > resident ? 1 : 0);
-    if (split_frames > a->n_frames) split_frames = a->n_frames;
-    args.split_from = a->n_frames - split_frames;
-    const long long units = (long long)a->n_streams * (args.split_from + 3LL * split_frames);
-    const unsigned grid = (unsigned)(units < resident ? units : resident);
     // Fewer streams than resident waves: the units of one stream would run one after the other and most of the
     // chip would idle.  Then every unit rebuilds its filter histories from the nine passes in front of it
     // (+2.9 % input) and all of them run at once.  NVX_INDEPENDENT=0/1 forces the choice (tests, A/B runs).
     static const int force = env_int("NVX_INDEPENDENT", -1);
     args.independent = force >= 0 ? force : (a->n_streams < resident && a->n_frames > 1);
+    // The last frame of a launch goes out in thirds when the launch is longer than one round of the grid: the waves that
+    // get no unit in the last round idle for a third of a frame instead of a whole one (4096 x 12: 4.1 % of all wave
+    // time was that idle tail).  r3: a launch of independent units that leaves two thirds of the chip idle even so -- one
+    // or a few channels replayed from a recording -- goes out in thirds THROUGHOUT: three times the units, each with its
+    // own nine-pass pre-roll (+8.6 % input), a third of the time.  NVX_TAIL_SPLIT=0: whole frames only; =n: the last n.
+    static const int tail_split = env_int("NVX_TAIL_SPLIT", -1);
+    const long long whole_units = (long long)a->n_streams * a->n_frames;
+    int split_frames = tail_split >= 0 ? tail_split : (whole_units > resident ? 1 : ((args.independent && 3 * whole_units <= resident) ? a->n_frames : 0));
+    if (split_frames > a->n_frames) split_frames = a->n_frames;
+    args.split_from = a->n_frames - split_frames;
+    const long long units = (long long)a->n_streams * (args.split_from + 3LL * split_frames);
+    const unsigned grid = (unsigned)(units < resident ? units : resident);
     // hand-over launches: a unit whose predecessor is still running rebuilds its histories instead of waiting for it
     // (NVX_DYNAMIC_PREROLL=0: it waits, as in round 1)
     static const int dynamic = env_int("NVX_DYNAMIC_PREROLL", 1);

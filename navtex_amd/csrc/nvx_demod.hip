@@ -415,11 +415,15 @@ extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_
 {
     const unsigned chains = a->part ? (unsigned)(2 * a->per_part * a->n_part) : (unsigned)a->n_slots;
     // Few chains and a long launch: one workgroup per tile instead of one per chain (NVX_DEMOD_TILES=0/1 forces the
-    // choice: tests, A/B runs).  Many chains keep the walk: the tile form does 2.3 x the arithmetic, and the headline's
-    // demodulator shares the chip with the next cascade launch.
+    // choice: tests, A/B runs).  Otherwise the walk: the tile form does 2.3 x the arithmetic in workgroups of 29 KB of
+    // LDS, which find no room on a CU beside the persistent grid of the NEXT cascade launch -- the demodulator runs
+    // beside it -- once that grid fills the chip (64 streams x 62 frames: step 3.1 ms with tiles, cascade + demodulator
+    // one after the other).  So: only while the launch's own cascade units (at most chains x frames) leave the chip
+    // at least half empty.
     static const int force = getenv("NVX_DEMOD_TILES") ? atoi(getenv("NVX_DEMOD_TILES")) : -1;
     const int tiles = (a->n3 + DTL - 1) / DTL;
-    const bool parallel = tiles >= 3 && (force >= 0 ? force != 0 : chains <= 512);
+    const long long chain_frames = (long long)chains * (a->n3 / NVX_Y3_PER_FRAME);
+    const bool parallel = tiles >= 3 && (force >= 0 ? force != 0 : chain_frames <= 2560);
     if (parallel) {
         const int wgs = tiles - 2;                           // one workgroup per tile from the third on; the head walks the first two
         hipLaunchKernelGGL(nvx_demod_front_head, dim3(chains), dim3(NVX_FRONT_THREADS), 0, s, *a);

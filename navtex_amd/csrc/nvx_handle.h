@@ -56,6 +56,7 @@ struct Result {                        // one in-flight launch's bit output
     // how many -- 0 = every stream (no list); the collect reads bits of the participants' chains only
     nvx_part *h_part = nullptr, *d_part = nullptr;
     int n_part = 0;
+    int n3 = 0;                        // 900 S/s samples per chain in the launch
     hipEvent_t copied = nullptr;       // push mode: the launch's host-to-device copies have left the staging sets
     hipEvent_t done = nullptr;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
