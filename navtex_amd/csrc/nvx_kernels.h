@@ -139,6 +139,7 @@ typedef struct {
     double2 *y3; size_t y3_cap, y3_base;
     int *queue, *status, *done;/* as nvx_cascade_args; done[n_wide]                                          */
     int independent;           /* set by the launcher: units pre-roll instead of waiting for their predecessor */
+    int thirds;                /* set by the launcher (independent units only): a unit is a third of a frame   */
 } nvx_wideband_args;
 
 #ifdef __cplusplus

@@ -51,7 +51,10 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     CascadeWave<2> cw;
     cw.init(&L.sub[wave], lane);
-    const int n_units = a.n_wide * a.n_frames;
+    // a unit = a frame, or (a.thirds: independent units only) a third of one -- 105 passes, every pending buffer empty there
+    // too (nvx_kernels.h), three times the units for launches that would leave most of the chip idle
+    const int per_frame = a.thirds ? 3 : 1, unit_passes = NVX_PASSES_PER_FRAME / per_frame, unit_y3 = NVX_Y3_PER_FRAME / per_frame;
+    const int n_units = a.n_wide * a.n_frames * per_frame;
     // channeliser: lane = (instant, component); instant m = 32 * wave + (lane >> 1) of the pass -> phase m & 7,
     // entry XH + (m >> 3) of every sub-band's window, component lane & 1
     const int xslot = ((lane >> 1) & 7) * XS + XH + 4 * wave + (lane >> 4);
@@ -68,7 +71,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         __syncthreads();
         const int u = L.unit;
         if (u >= n_units) break;
-        const int part = u / a.n_wide;                  // frame of the launch
+        const int part = u / a.n_wide;                  // frame (or third of a frame) of the launch
         const int entry = u - part * a.n_wide;          // position in the launch's list of participants (nvx_kernels.h, nvx_part)
         int w = entry, parity = 0;                      // wideband stream, and which of its state blocks it reads
         if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); w = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
@@ -80,7 +83,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         const bool preroll = a.independent && part > 0;
         const int pre = preroll ? NVX_PREROLL_PASSES : 0;
         // the input does not depend on the predecessor: request this wave's piece of the first pass now
-        const uint32_t *unit0 = a.raw + ((size_t)w * a.pitch + a.first_sample) + ((size_t)part * NVX_PASSES_PER_FRAME - (size_t)pre) * WB_PASS_WORDS;
+        const uint32_t *unit0 = a.raw + ((size_t)w * a.pitch + a.first_sample) + ((size_t)part * unit_passes - (size_t)pre) * WB_PASS_WORDS;
         const u32x4 *src = (const u32x4 *)unit0 + wave * 64 + lane;
         u32x4 pf = __builtin_nontemporal_load(src);
 
@@ -109,8 +112,10 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         // ------------------------------------------------------ state in (sc1 loads)
         double2 *st = (double2 *)((parity ? a.state[0] : a.state[1]) + (size_t)s * NVX_CASCADE_STATE_BYTES);
         const double2 *st_in = (part == 0) ? (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)s * NVX_CASCADE_STATE_BYTES) : st;
-        // (a frame starts at mixer index 0, and so does a pre-roll: 9 * 64 = 0 mod 9; FIR3 outputs of the pre-roll are not written)
-        cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_Y3_PER_FRAME, a.y3_cap, 0,
+        // (a frame starts at mixer index 0, a third at 6720 * third mod 9, and a pre-roll 9 * 64 = 0 mod 9 outputs earlier at
+        // the same index; FIR3 outputs of the pre-roll are not written)
+        cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * unit_y3, a.y3_cap,
+                      a.thirds ? ((part % 3) * (NVX_THIRD_PASSES * 64)) % NVX_MIX_N : 0,
                       preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
         NVX_WAVE_LDS_FENCE();
         if (!preroll) cw.state_in(st_in); else cw.state_zero();
@@ -124,7 +129,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
             }
         }
 
-        const int n_pass = pre + NVX_PASSES_PER_FRAME;
+        const int n_pass = pre + unit_passes;
         for (int pass = 0; pass < n_pass; pass++) {
             if (pass == pre) { cw.emit = true; cw.n3_done = 0; }
             // ---- 1. this wave's 1 KiB of the pass into the raw window; next pass's piece requested
@@ -151,7 +156,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         // ------------------------------------------------------ state out (sc1 stores), publish
         // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
-        if (!a.independent || part + 1 == a.n_frames) {
+        if (!a.independent || part + 1 == a.n_frames * per_frame) {
             cw.state_out(st);
             if (wave == 7 && lane < 40)
                 __hip_atomic_store((parity ? a.hist[0] : a.hist[1]) + (size_t)w * 40 + lane, L.raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -190,12 +195,16 @@ extern "C" hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipS
     hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_wide) * sizeof(int), s);
     if (e != hipSuccess) return e;
     const long long units = (long long)a->n_wide * a->n_frames;
-    const unsigned grid = (unsigned)(units < resident ? units : resident);
     // Fewer streams than resident workgroups: independent units (pre-roll instead of hand-over), all frames at once.
     // NVX_INDEPENDENT=0/1 forces the choice (tests, A/B runs), as for the cascade kernel.
     nvx_wideband_args args = *a;
     static const int force = getenv("NVX_INDEPENDENT") ? atoi(getenv("NVX_INDEPENDENT")) : -1;
     args.independent = force >= 0 ? force : (a->n_wide < resident && a->n_frames > 1);
+    // ... and in thirds when even that leaves two thirds of the chip idle (one RSP capture replayed).  NVX_TAIL_SPLIT=0: whole frames.
+    static const int no_thirds = getenv("NVX_TAIL_SPLIT") && atoi(getenv("NVX_TAIL_SPLIT")) == 0;
+    args.thirds = args.independent && !no_thirds && 3 * units <= resident;
+    const long long all_units = units * (args.thirds ? 3 : 1);
+    const unsigned grid = (unsigned)(all_units < resident ? all_units : resident);
     hipLaunchKernelGGL(nvx_wideband_fused, dim3(grid), dim3(512), 0, s, args);
     return hipGetLastError();
 }
