@@ -85,12 +85,12 @@ __device__ __forceinline__ double front_dphi(double2 s, double2 p)
 }
 // mark/space decision for a window ENDING at sample t, decoder.C:115-132: float*float product, double*float product,
 // double sum, accumulate in double, round to float -- five samples, filter index 0..4
-__device__ __forceinline__ unsigned char front_decision(const double2 (&win)[5])     // win[i] = sample t - 4 + i
+__device__ __forceinline__ unsigned char front_decision(double2 w0, double2 w1, double2 w2, double2 w3, double2 w4)     // w_i = sample t - 4 + i
 {
     float BR = 0.0f, BI = 0.0f, YR = 0.0f, YI = 0.0f;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-        const double2 w = win[i];
+        const double2 w = i == 0 ? w0 : i == 1 ? w1 : i == 2 ? w2 : i == 3 ? w3 : w4;
         const float fR = NVX_BF_R[i], fI = NVX_BF_I[i];
         const double sampleR = w.x, sampleI = w.y;
         YR = (float)((double)YR + ((double)((float)sampleR * fR) - sampleI * (double)fI));
@@ -225,11 +225,11 @@ __device__ __forceinline__ void front_sequential(const nvx_demod_args &a, int ch
         const unsigned long long gt = ch.g0 + (unsigned long long)ta;    // g of L = 0
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             const int t = ta + L;
-            const double2 win[5] = { y3_at(y3, hist, t - 4), y3_at(y3, hist, t - 3), y3_at(y3, hist, t - 2), y3_at(y3, hist, t - 1), y3[t] };
-            const double ds = front_dphi(win[4], win[3]);
+            const double2 w3 = y3_at(y3, hist, t - 1), w4 = y3[t];
+            const double ds = front_dphi(w4, w3);
             s_dphi[8 + L] = ds;
             if (dphi_out) dphi_out[t] = ds;
-            s_D[L] = front_decision(win);
+            s_D[L] = front_decision(y3_at(y3, hist, t - 4), y3_at(y3, hist, t - 3), y3_at(y3, hist, t - 2), w3, w4);
         }
         __syncthreads();
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS)
@@ -313,8 +313,7 @@ __global__ __launch_bounds__(NVX_FRONT_THREADS) void nvx_demod_front_tiles(nvx_d
         p_dphi[i] = ds;
         if (i >= FRONT_LOOKBACK) {
             if (dphi_out) dphi_out[t] = ds;
-            const double2 win[5] = { y3[t - 4], y3[t - 3], y3[t - 2], y3[t - 1], y3[t] };      // t - 4 >= 0: no history needed
-            p_D[i - FRONT_LOOKBACK] = front_decision(win);
+            p_D[i - FRONT_LOOKBACK] = front_decision(y3[t - 4], y3[t - 3], y3[t - 2], y3[t - 1], y3[t]);      // t - 4 >= 0: no history needed
         }
     }
     __syncthreads();
