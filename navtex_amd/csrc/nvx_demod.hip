@@ -381,33 +381,20 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
     // one row of 16-bit words per chain: eight bit periods per 16-byte load, requested one group ahead
     const uint4 *words = (const uint4 *)(a.words + (size_t)slot * (a.y3_cap / 9));
-    // The slew limiter's chain (prev_offset) is independent of the bit FSM's: it runs one group of eight periods AHEAD,
-    // in arithmetic, beside the table lookups of the bit FSM -- whose dependent LDS round trip per period is what a
-    // long launch of few chains waits for (one channel x 62 frames: 208 us with both chains in one).
-    auto unpack = [](uint4 wv, unsigned (&w)[8]) {
-        w[0] = wv.x & 0xffffu; w[1] = wv.x >> 16; w[2] = wv.y & 0xffffu; w[3] = wv.y >> 16;
-        w[4] = wv.z & 0xffffu; w[5] = wv.z >> 16; w[6] = wv.w & 0xffffu; w[7] = wv.w >> 16;
-    };
-    unsigned wcur[8], tcur[8], wnx[8], tnx[8];
-    unpack(words[0], wcur);
-#pragma unroll
-    for (int i = 0; i < 8; i++) tcur[i] = nvx_fsm_timing_step(wcur[i], &r.prev_offset);
-    uint4 wnext = periods > 8 ? words[1] : words[0];
+    uint4 wnext = words[0];
 
     for (int m0 = 0; m0 < periods; m0 += 8) {     // periods is a multiple of 32
-        const bool more = m0 + 8 < periods;
-        if (more) unpack(wnext, wnx);
-        if (m0 + 16 < periods) wnext = words[m0 / 8 + 2];
+        const uint4 wv = wnext;
+        if (m0 + 8 < periods) wnext = words[m0 / 8 + 1];
+        const unsigned wcur[8] = { wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16,
+                                   wv.z & 0xffffu, wv.z >> 16, wv.w & 0xffffu, wv.w >> 16 };
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            if (more) tnx[i] = nvx_fsm_timing_step(wnx[i], &r.prev_offset);      // limiter of the NEXT group ...
             int n;
-            const unsigned b = nvx_fsm_bit_period(s_tab, wcur[i], tcur[i], &r, &n);      // ... beside this group's lookups
+            const unsigned b = nvx_fsm_period(s_tab, wcur[i], &r, &n);
             acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
             nacc += n;
         }
-#pragma unroll
-        for (int i = 0; i < 8; i++) { wcur[i] = wnx[i]; tcur[i] = tnx[i]; }
         // at most 10 bits per 8 periods: one store check per group
         if (nacc >= 32) {
             if (nwords < cap_words) bits[nwords] = (unsigned)acc;

@@ -112,30 +112,6 @@ typedef struct nvx_fsm_regs {
     int prev_offset;     /* slew limiter state, -1 before the first decision           */
 } nvx_fsm_regs;
 
-/* The two halves of a bit period, for callers that pipeline them (the FSM kernel): the slew limiter's chain
- * (prev_offset) does not depend on the bit FSM's, so the limiter of period m + 1 can run beside the table lookup of
- * period m.  nvx_fsm_timing_step: arithmetic, no table (the table's entries are generated from the same function);
- * returns the new sync offset in bits 0-3 and "decision made" in bit 4.                                             */
-NVX_FSM_HD unsigned nvx_fsm_timing_step(unsigned w, int *prev_offset)
-{
-    const unsigned raw = w >> 12;
-    int offset = 0;
-    const int have = nvx_fsm_timing(raw > 9u ? 15 : (int)raw, prev_offset, &offset);
-    return (unsigned)offset | ((unsigned)have << 4);
-}
-NVX_FSM_HD unsigned nvx_fsm_bit_period(const uint32_t *tab, unsigned w, unsigned tstep, nvx_fsm_regs *r, int *n_out)
-{
-    const int have = (int)((tstep >> 4) & 1u);
-    const int nso_new = have ? (int)(tstep & 15u) : r->nso;
-    const int live = have | (r->so != NVX_FSM_UNSYNCED);     /* unsynced and no decision this period either: nothing can happen */
-    const uint32_t e = tab[NVX_FSM_KEY(r->phase1, r->so, r->nso, nso_new)];
-    r->phase1 = live ? NVX_FSM_E_PHASE1(e) : r->phase1;
-    r->so = live ? NVX_FSM_E_SO(e) : r->so;
-    r->nso = nso_new;
-    *n_out = live ? NVX_FSM_E_N(e) : 0;
-    return ((w >> NVX_FSM_E_K1(e)) & 1u) | (((w >> NVX_FSM_E_K2(e)) & 1u) << 1);
-}
-
 /* One bit period.  w = the front kernel's word: bits 0..8 the mark/space decision if a window
  * ended on sample k ('B' = 1), bits 12..15 the arg-max of the timing evaluation (15 = none).
  * Returns the decided bits in the low *n_out (0..2) positions, first decision lowest.       */

@@ -28,7 +28,6 @@ extern "C" int nvx_fsm_selftest(uint32_t seed, int periods)
     // per-sample registers (the reference's variables) and per-period registers
     int synced = 0, sync_off = 0, next_sync_off = 0, phase = -1, prev_a = -1;
     nvx_fsm_regs r = { 0, NVX_FSM_UNSYNCED, 0, -1 };
-    nvx_fsm_regs r2 = { 0, NVX_FSM_UNSYNCED, 0, -1 };        // the pipelined halves the FSM kernel uses (limiter, then table)
     const int lead = (int)(rnd() % 70u);                     // periods before the class sums are primed
     int raw = (int)(rnd() % 9u), bad = 0;
     for (int m = 0; m < periods; m++) {
@@ -51,10 +50,6 @@ extern "C" int nvx_fsm_selftest(uint32_t seed, int periods)
         int n_got;
         const unsigned got = nvx_fsm_period(tab, w, &r, &n_got) & ((1u << n_got) - 1u);
         if (n_got != n_want || got != want) bad++;
-        int n_got2;
-        const unsigned tstep = nvx_fsm_timing_step(w, &r2.prev_offset);
-        const unsigned got2 = nvx_fsm_bit_period(tab, w, tstep, &r2, &n_got2) & ((1u << n_got2) - 1u);
-        if (n_got2 != n_want || got2 != want || r2.phase1 != r.phase1 || r2.so != r.so || r2.nso != r.nso || r2.prev_offset != r.prev_offset) bad++;
         if (r.phase1 != phase + 1 || r.nso != next_sync_off || r.prev_offset != prev_a ||
             (r.so != NVX_FSM_UNSYNCED) != (synced != 0) || (synced && r.so != sync_off)) bad++;
     }
