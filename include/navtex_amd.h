@@ -256,6 +256,14 @@ NVX_API int   nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, ui
 /* hand-over statistics of the FIR-cascade work queue over the collected launches: how many units had to
  * wait for the previous frame of their stream, and how many polls (about 1 us each) they spent waiting  */
 NVX_API int   nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *units_waited, uint64_t *launches, int reset);
+/* Integrity of the carried filter state (the reference keeps it in statics: receiver/fir1cpp.C:51-60,
+ * receiver/fir2cpp.C:74-83, receiver/fir3cpp.h:90-95; here it travels between work units through HBM).  Every state
+ * block carries a 64-bit word over its contents and its position; a unit recomputes it over what it loaded.
+ * stale_repaired: hand-overs INSIDE a launch whose block failed the check -- the unit rebuilt its histories from its
+ * own input instead (bit-identical results) -- expected 0; launch_failures: launches whose inherited state failed the
+ * check (the call that collects such a launch returns NVX_ERR_HIP and its bits are discarded; nvx_reset recovers);
+ * launches: launches collected so far (as nvx_cascade_wait_stats).  reset != 0 clears the two counters afterwards. */
+NVX_API int   nvx_cascade_integrity_stats(nvx_handle *h, uint64_t *stale_repaired, uint64_t *launch_failures, uint64_t *launches, int reset);
 /* How close the demodulator's bit-timing decisions came to a tie since create / reset.  The arg-max over the nine
  * class sums (receiver/decoder.C:202-215, strict '>') is the one decision of the path that rests on delta-phi values
  * which may differ from glibc's atan2 in the last bit; such a difference can only matter where the best sum and the
@@ -270,6 +278,11 @@ NVX_API int   nvx_demod_tie_stats(nvx_handle *h, uint64_t *near_ties, uint64_t *
 NVX_API int   nvx_fsm_selftest(uint32_t seed, int periods);
 /* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */
 NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
+/* test / diagnostics hook: the carried FIR state block of one decoded stream -- the block the stream's NEXT launch will
+ * read: filter histories as fp64 pairs, then the seal (nvx_cascade_integrity_stats) -- copied to host memory (write = 0)
+ * or replaced from it (write = 1); `bytes` must be NVX_STATE_BLOCK_BYTES.  Synchronises with the handle's launches.     */
+#define NVX_STATE_BLOCK_BYTES 4352
+NVX_API int    nvx_debug_cascade_state(nvx_handle *h, int stream, void *buf, size_t bytes, int write);
 /* debug tap: copy the 900 S/s FIR-cascade output of the LAST launch for one
  * (stream, chain) to host: out[2*k], out[2*k+1] = I,Q; returns sample count  */
 NVX_API size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out, size_t cap_pairs);

@@ -247,6 +247,13 @@ class Pipeline:
         N.check(lib.nvx_cascade_wait_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_wait_stats")
         return a.value, b.value, c.value
 
+    def integrity_stats(self, reset: bool = False) -> Tuple[int, int, int]:
+        """(hand-overs whose state block failed its seal and were repaired by a pre-roll, launches whose inherited state
+        failed it, launches collected) -- nvx_cascade_integrity_stats; the first two are expected to be 0."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(lib.nvx_cascade_integrity_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_integrity_stats")
+        return a.value, b.value, c.value
+
     def tie_stats(self) -> Tuple[int, int, float]:
         """(near ties, evaluations, smallest relative margin) of the bit-timing arg-max since create / reset."""
         a, b, m = C.c_uint64(), C.c_uint64(), C.c_double()
@@ -267,6 +274,18 @@ class Pipeline:
         s, n = C.c_double(), C.c_uint64()
         N.check(lib.nvx_kernel_time_stats(self._h, which, C.byref(s), C.byref(n), int(reset)), "nvx_kernel_time_stats")
         return s.value, n.value
+
+    STATE_BLOCK_BYTES = 4352
+
+    def debug_state(self, stream: int = 0) -> np.ndarray:
+        """The carried FIR state block the stream's next launch will read, as 544 uint64 (nvx_debug_cascade_state)."""
+        out = np.empty(self.STATE_BLOCK_BYTES // 8, dtype=np.uint64)
+        N.check(lib.nvx_debug_cascade_state(self._h, stream, N.as_ptr(out), out.nbytes, 0), "nvx_debug_cascade_state")
+        return out
+
+    def debug_set_state(self, stream: int, block: np.ndarray) -> None:
+        block = np.ascontiguousarray(block, dtype=np.uint64)
+        N.check(lib.nvx_debug_cascade_state(self._h, stream, N.as_ptr(block), block.nbytes, 1), "nvx_debug_cascade_state")
 
     def debug_y3(self, stream: int = 0, chain: int = 0) -> np.ndarray:
         out = np.empty((self.max_frames * FRAME_Y3, 2), dtype=np.float64)

@@ -61,7 +61,9 @@ def _load() -> C.CDLL:
         "nvx_StreamACallback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
         "nvx_capture_start": (i, [vp, i, C.c_double, C.POINTER(vp)]), "nvx_capture_callback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
         "nvx_capture_stop": (i, [vp]), "nvx_capture_record": (i, [vp, C.c_char_p]), "nvx_fsm_selftest": (i, [u32, i]),
-        "nvx_cascade_wait_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]), "nvx_capture_pause": (None, [vp, i]),
+        "nvx_cascade_wait_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]),
+        "nvx_debug_cascade_state": (i, [vp, i, vp, sz, i]),
+        "nvx_cascade_integrity_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]), "nvx_capture_pause": (None, [vp, i]),
         "nvx_capture_stats": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "nvx_config_default": (None, [C.POINTER(Config)]),
         "nvx_create": (i, [C.POINTER(Config), C.POINTER(vp)]), "nvx_destroy": (None, [vp]), "nvx_reset": (i, [vp]),

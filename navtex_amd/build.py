@@ -84,6 +84,39 @@ def build_lib(force: bool = False) -> Path:
     return LIB
 
 
+def build_variant(name: str, flags, sources=("nvx_cascade.hip", "nvx_wideband_fused.hip")) -> Path:
+    """TEST INFRASTRUCTURE: another build of the same library -- the named kernel sources recompiled with extra flags,
+    everything else the product's own objects -- as tests/_variants/libnavtex_amd_<name>.so; load it with
+    NAVTEX_AMD_LIB.  `inject` (-DNVX_INJECT_STALE=n) is the fault-injection build of the state hand-over's seal."""
+    hipcc = _hipcc()
+    build_lib()
+    out_dir = ROOT / "tests" / "_variants"
+    out_dir.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + [ROOT / "include" / "navtex_amd.h", Path(__file__)]
+    objs, jobs = [], []
+    for src in C_SOURCES + HIP_SOURCES + CXX_SOURCES:
+        if src in sources:
+            o = out_dir / f"{src}.{name}.o"
+            if _stale(o, [CSRC / src] + headers):
+                lang = ["-x", "c", "-std=gnu11"] if src in C_SOURCES else (["-x", "hip"] if src in CXX_SOURCES else []) + [f"--offload-arch={ARCH}", "-std=c++17"]
+                jobs.append([hipcc, *lang, *COMMON, *flags, "-c", CSRC / src, "-o", o])
+            objs.append(o)
+        else:
+            objs.append(OBJ / (src + ".o"))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        list(pool.map(_run, jobs))
+    lib = out_dir / f"libnavtex_amd_{name}.so"
+    if _stale(lib, objs):
+        tmp = lib.with_name(lib.name + f".tmp{os.getpid()}")
+        _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp, "-lpthread", "-ldl"])
+        os.replace(tmp, lib)
+    return lib
+
+
+INJECT_FLAGS = ["-DNVX_INJECT_STALE=5"]
+
+
 def build_oracle() -> None:
     """Test infrastructure: our CPU restatement, and the reference itself when its
     sources are present (build container only)."""
@@ -96,3 +129,11 @@ if __name__ == "__main__":
     build_lib(force="--force" in sys.argv)
     if "--oracle" in sys.argv:
         build_oracle()
+    if "--inject" in sys.argv:
+        build_variant("inject", INJECT_FLAGS)
+    if "--variant" in sys.argv:               # --variant NAME FLAG... [--sources a.hip,b.cpp]: A/B builds (tests/_variants/)
+        rest = sys.argv[sys.argv.index("--variant") + 1:]
+        srcs = ("nvx_cascade.hip", "nvx_wideband_fused.hip")
+        if "--sources" in rest:
+            k = rest.index("--sources"); srcs = tuple(rest[k + 1].split(",")); rest = rest[:k] + rest[k + 2:]
+        print(build_variant(rest[0], rest[1:], srcs))

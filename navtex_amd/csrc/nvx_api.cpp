@@ -175,8 +175,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMalloc(&h->d_ctrl, (size_t)(NVX_CASCADE_CTRL_INTS + h->n_streams) * sizeof(int)));
     CR_TRY(hipMalloc(&h->d_ties, sizeof(nvx_tie_stats)));
     CR_TRY(hipHostMalloc((void **)&h->h_ties, sizeof(nvx_tie_stats), hipHostMallocDefault));
-    CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * 3 * sizeof(int), hipHostMallocDefault));
-    memset(h->h_status, 0, RESULT_SLOTS * 3 * sizeof(int));
+    CR_TRY(hipHostMalloc((void **)&h->h_status, RESULT_SLOTS * NVX_STATUS_INTS * sizeof(int), hipHostMallocDefault));
+    memset(h->h_status, 0, RESULT_SLOTS * NVX_STATUS_INTS * sizeof(int));
     for (auto &r : h->res) {
         CR_TRY(hipMalloc(&r.d_bits, (size_t)h->n_slots * h->bits_cap));
         CR_TRY(hipMalloc(&r.d_nbits, (size_t)h->n_slots * sizeof(int)));
@@ -366,6 +366,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
     ca.stage0_order = h->cfg.stage0_order;
+    ca.third0 = (unsigned)(h->g0s[0] / (NVX_FRAME_Y3 / 3));        // the state blocks' tag (nvx_kernels.h): position in thirds of a frame
     ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : (demod_overlap > 1 ? demod_overlap : (demod_overlap == 1 ? -1 : 0));
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
@@ -387,7 +388,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
         wa.state[0] = ca.state[0]; wa.state[1] = ca.state[1];
         wa.hist[0] = h->d_whist[p0]; wa.hist[1] = h->d_whist[p0 ^ 1];       // a stream reads [its parity], writes the other
         wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
-        wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done;
+        wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done; wa.third0 = ca.third0;
         HIP_TRY(nvx_launch_wideband_fused(&wa, st));
         h->wide_launches++;
     } else {
@@ -395,7 +396,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     }
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
     if (h->cfg.wideband && !fused) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
-    HIP_TRY(hipMemcpyAsync(h->h_status + 3 * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->h_status + NVX_STATUS_INTS * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, NVX_STATUS_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
     // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
     if (sd != st) HIP_TRY(hipStreamWaitEvent(sd, h->casc_done[yb], 0));
@@ -462,10 +463,18 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
         Result &r = h->res[h->collected % RESULT_SLOTS];
         if (r.pending) {
             HIP_TRY(hipEventSynchronize(r.done));
-            const int *stat = h->h_status + 3 * (h->collected % RESULT_SLOTS);
+            const int *stat = h->h_status + NVX_STATUS_INTS * (h->collected % RESULT_SLOTS);
             h->wait_polls += (uint64_t)(unsigned)stat[1]; h->wait_units += (uint64_t)(unsigned)stat[2]; h->wait_launches++;
+            h->stale_repaired += (uint64_t)(unsigned)stat[3];
             if (stat[0] != 0) {
-                nvx_set_error("FIR cascade work queue: a wait on the previous frame of a stream timed out");
+                // (the launch's bits are not taken in: whatever it produced rests on a state nobody vouches for)
+                if (stat[0] == NVX_STATUS_INTEGRITY) {
+                    h->integrity_failures++;
+                    nvx_set_error("FIR cascade: the filter state a launch inherited from its predecessor failed its integrity word (nvx_reset the handle)");
+                } else {
+                    nvx_set_error("FIR cascade work queue: a wait on the previous frame of a stream timed out");
+                }
+                r.pending = false; h->collected++;
                 return NVX_ERR_HIP;
             }
             if (r.timed) {
@@ -601,6 +610,17 @@ extern "C" int nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *
     return NVX_OK;
 }
 
+extern "C" int nvx_cascade_integrity_stats(nvx_handle *h, uint64_t *stale_repaired, uint64_t *launch_failures, uint64_t *launches, int reset)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (stale_repaired) *stale_repaired = h->stale_repaired;
+    if (launch_failures) *launch_failures = h->integrity_failures;
+    if (launches) *launches = h->wait_launches;
+    if (reset) h->stale_repaired = h->integrity_failures = 0;
+    return NVX_OK;
+}
+
 extern "C" int nvx_demod_tie_stats(nvx_handle *h, uint64_t *near_ties, uint64_t *evaluations, double *min_margin)
 {
     if (!h) return NVX_ERR_ARG;
@@ -625,6 +645,21 @@ extern "C" int nvx_enable_debug(nvx_handle *h, int enabled)
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (enabled && !h->d_dphi) HIP_TRY(hipMalloc(&h->d_dphi, (size_t)h->n_slots * h->y3_cap * sizeof(double)));
     if (!enabled && h->d_dphi) { hipFree(h->d_dphi); h->d_dphi = nullptr; }
+    return NVX_OK;
+}
+
+static_assert(NVX_STATE_BLOCK_BYTES == NVX_CASCADE_STATE_BYTES, "public size of a state block");
+extern "C" int nvx_debug_cascade_state(nvx_handle *h, int stream, void *buf, size_t bytes, int write)
+{
+    if (!h || !buf || stream < 0 || stream >= h->n_streams || bytes != (size_t)NVX_CASCADE_STATE_BYTES) { nvx_set_error("nvx_debug_cascade_state: bad argument (a block is %d bytes)", NVX_CASCADE_STATE_BYTES); return NVX_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int in = h->cfg.wideband ? stream / NVX_WB_SUBBANDS : stream;      // the input stream whose parity the block follows
+    uint8_t *blk = h->d_cstate[h->parity[in]] + (size_t)stream * NVX_CASCADE_STATE_BYTES;
+    if (write) HIP_TRY(hipMemcpy(blk, buf, bytes, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemcpy(buf, blk, bytes, hipMemcpyDeviceToHost));
     return NVX_OK;
 }
 

@@ -253,10 +253,12 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         int stream = entry;
         const uint8_t *state_rd = a.state[0];
         uint8_t *state_wr = a.state[1];
+        unsigned third0 = a.third0;                    // where the launch starts in the stream, in thirds of a frame since reset
         if (LIST) {
             const unsigned long long e = nvx_load_const_u64(a.part + entry);      // { stream, parity }
             stream = (int)(unsigned)e;
             if (e >> 32) { state_rd = a.state[1]; state_wr = a.state[0]; }
+            third0 = (unsigned)(nvx_load_const_u64(&a.part[entry].g0) / NVX_THIRD_Y3);
         }
         int *const done = a.done + entry;              // hand-over flag of this stream within the launch
         const unsigned mask = a.chain_masks[stream];
@@ -294,7 +296,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
                     __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (!ok) {                                   // give up loudly rather than hang the GPU
-                    if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(a.status, NVX_STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
 #ifdef NVX_HANDOFF_FENCES
@@ -306,12 +308,6 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
 #endif
             }
         }
-        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
-        const int n_pass = pre + thirds * NVX_THIRD_PASSES;
-        const u32x4 *src = unit0 - (size_t)pre * pass_stride;
-        if (preroll) load_pass<RAW, NT>(pfA, src);
-        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
-        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
 
         // ------------------------------------------------------ state in
         // A stream's first unit of a launch reads the block the stream's previous launch left (state[parity]); every
@@ -319,21 +315,54 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         // a launch never reads and writes the same block through different units (the independent units run in any order).
         double2 *st = (double2 *)(state_wr + (size_t)stream * NVX_CASCADE_STATE_BYTES);
         const double2 *st_in = (part == 0) ? (const double2 *)(state_rd + (size_t)stream * NVX_CASCADE_STATE_BYTES) : st;
+#ifdef NVX_INJECT_STALE
+        // fault-injection build (tests): every NVX_INJECT_STALE-th unit that takes over from a predecessor reads the OTHER
+        // block instead -- what the stream's previous launch left there, a well-formed block of an earlier position: a
+        // stale hand-over in its purest form.  The seal must catch every one of them and the results must not change.
+        if (part > 0 && !preroll && (u % NVX_INJECT_STALE) == 0) st_in = (const double2 *)(state_rd + (size_t)stream * NVX_CASCADE_STATE_BYTES);
+#endif
+        cw.set_mask(mask);
+        unsigned long long ct = 0;                     // S0 == 3: (C, t) of the predecessor's last lane pair, or silence in front of a pre-roll
+        if (!preroll) {
+            NVX_WAVE_LDS_FENCE();
+            const unsigned long long sealed = seal_load(st_in);
+            unsigned long long fold = cw.state_in(st_in);
+            if (S0 == 3 && s0.last_pair) {
+                ct = __hip_atomic_load((const unsigned long long *)(st_in + NVX_STATE_CIC3) + (lane & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fold ^= seal_rotc<37>(ct);
+            }
+            // The seal (nvx_kernels.h): what was loaded must be what the predecessor stored, whole and of the right position.
+            // (a stream at position 0 has the zeros of nvx_reset in front of it: nothing was ever stored there)
+            const unsigned third_in = third0 + (unsigned)part;
+            if (third_in != 0 && !seal_ok(sealed, wave_fold64(fold), stream, third_in)) {
+                if (part == 0) {
+                    // inherited through a kernel boundary, not through the fence-free hand-over, and nothing to fall back
+                    // on (the samples in front of the launch are gone): the launch is reported as failed (the unit runs
+                    // on, so that its successors are not left waiting; the host discards the launch's results)
+                    if (lane == 0) __hip_atomic_store(a.status, NVX_STATUS_INTEGRITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    // a stale or torn hand-over: the unit rebuilds its histories from its own input instead (the
+                    // independent units' pre-roll: bit-identical by construction) and the event is counted
+                    preroll = true; ct = 0;
+                    if (lane == 0) __hip_atomic_fetch_add(a.status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
+        const int n_pass = pre + thirds * NVX_THIRD_PASSES;
+        const u32x4 *src = unit0 - (size_t)pre * pass_stride;
+        if (preroll) load_pass<RAW, NT>(pfA, src);
+        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
+        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start; the pre-roll starts
         // 576 = 0 mod 9 outputs earlier: same index); FIR3 outputs of the pre-roll are not written
         cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_THIRD_Y3, a.y3_cap,
                       ((part % 3) * (NVX_THIRD_PASSES * 64)) % NVX_MIX_N,
                       preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
         NVX_WAVE_LDS_FENCE();
-        if (!preroll) cw.state_in(st_in); else cw.state_zero();
+        if (preroll) cw.state_zero();
         NVX_WAVE_LDS_FENCE();
-        if (S0 == 3) {
-            // the two blocks in front of the unit: (C, t) of the predecessor's last lane pair, or silence in front of a pre-roll
-            unsigned long long ct = 0;
-            if (!preroll && s0.last_pair)
-                ct = __hip_atomic_load((const unsigned long long *)(st_in + NVX_CASCADE_STATE_ENTRIES - 1) + (lane & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s0.c_prev = (int)(unsigned)ct; s0.t_prev = (int)(unsigned)(ct >> 32);
-        }
+        if (S0 == 3) { s0.c_prev = (int)(unsigned)ct; s0.t_prev = (int)(unsigned)(ct >> 32); }
 
         auto body = [&](u32x4 (&pf)[NPF], const int pass) {
             // ---- 1. new 252 kS/s samples into the polyphase window ----------
@@ -387,16 +416,20 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
             } while (!ok && ++spins < NVX_SPIN_LIMIT);
             if (spins > 0 && lane == 0) __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!ok) {
-                if (lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(a.status, NVX_STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
             asm volatile("" ::: "memory");
         }
         if (!a.independent || part + thirds == 3 * a.n_frames) {
-            cw.state_out(st);
-            if (S0 == 3 && s0.last_pair)
-                __hip_atomic_store((unsigned long long *)(st + NVX_CASCADE_STATE_ENTRIES - 1) + (lane & 1),
-                                   (unsigned long long)(unsigned)s0.c_prev | ((unsigned long long)(unsigned)s0.t_prev << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long fold = cw.state_out(st);
+            if (S0 == 3 && s0.last_pair) {
+                const unsigned long long ct_out = (unsigned long long)(unsigned)s0.c_prev | ((unsigned long long)(unsigned)s0.t_prev << 32);
+                __hip_atomic_store((unsigned long long *)(st + NVX_STATE_CIC3) + (lane & 1), ct_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fold ^= seal_rotc<37>(ct_out);
+            }
+            fold = wave_fold64(fold);
+            if (lane == 0) seal_store(st, fold, stream, third0 + (unsigned)(part + thirds));
         }
         // publish: the state stores (write-through, sc1) have completed at device level once vmcnt is 0; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

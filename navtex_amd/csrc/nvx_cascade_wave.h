@@ -152,6 +152,79 @@ __device__ __forceinline__ void state_store(double2 *p, double2 v)
     __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- the state block's seal (nvx_kernels.h): every 8-byte pattern a unit stores, rotated by its position in the block
+// and XOR-folded over the wave, mixed with the block's tag (stream, position of the stream in thirds of a frame).
+// Position = (slot of the entry in the lane's list: a compile-time rotation) and (lane: the rotations of the butterfly
+// below) -- no lane-dependent shift counts, which the compiler would keep in VGPRs across the whole kernel (the
+// headline kernel sits 9 registers under its occupancy limit).
+template <int R> __device__ __forceinline__ unsigned long long seal_rotc(unsigned long long v)
+{
+    constexpr int r = R & 63;
+    if constexpr (r == 0) return v;
+    else return (v << r) | (v >> (64 - r));
+}
+template <int SLOT> __device__ __forceinline__ unsigned long long seal_pair(double2 v)
+{
+    return seal_rotc<14 * SLOT + 3>((unsigned long long)__double_as_longlong(v.x)) ^ seal_rotc<14 * SLOT + 10>((unsigned long long)__double_as_longlong(v.y));
+}
+__device__ __forceinline__ unsigned long long seal_tag(int stream, unsigned third)
+{
+    unsigned long long t = ((unsigned long long)(unsigned)stream << 32) | third;
+    t *= 0x9E3779B97F4A7C15ull; t ^= t >> 29; t *= 0xBF58476D1CE4E5B9ull; t ^= t >> 32;
+    return t;
+}
+// A wave-uniform XOR over the lanes l of rot(v_l, r(l)) with r distinct for every lane.  Within a row of 16 lanes four
+// DPP exchanges, each rotating what it takes in: lane ^ 1 (by 1), lane ^ 2 (by 2), mirror of the half row (by 4), mirror
+// of the row (by 8) -- lane 0 of a row ends with every lane of the row under its own rotation 0..15 (the subset sums of
+// 1, 2, 4, 8 along the lane's path); the four rows meet in scalar registers under rotations 0, 16, 32, 48.  DPP moves and
+// v_readlane take immediates: no index register lives in a VGPR across the kernel (as __shfl_xor's would), and no trip
+// through the LDS crossbar sits between a unit's state loads and its first pass.  All lanes active.
+template <int CTRL, int R> __device__ __forceinline__ unsigned long long seal_step(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return v ^ seal_rotc<R>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long seal_row(unsigned lo, unsigned hi, int lane0)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, lane0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, lane0);
+}
+__device__ __forceinline__ unsigned long long wave_fold64(unsigned long long v)
+{
+    v = seal_step<0xB1, 1>(v);           // quad_perm [1,0,3,2]
+    v = seal_step<0x4E, 2>(v);           // quad_perm [2,3,0,1]
+    v = seal_step<0x141, 4>(v);          // row_half_mirror
+    v = seal_step<0x140, 8>(v);          // row_mirror
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    return seal_row(lo, hi, 0) ^ seal_rotc<16>(seal_row(lo, hi, 16)) ^ seal_rotc<32>(seal_row(lo, hi, 32)) ^ seal_rotc<48>(seal_row(lo, hi, 48));
+}
+#ifdef NVX_SEAL_OFF
+// A/B build (what the seal costs): the blocks carry no seal and nothing is checked
+#define wave_fold64(v) (v)
+__device__ __forceinline__ void seal_store(double2 *, unsigned long long, int, unsigned) {}
+__device__ __forceinline__ unsigned long long seal_load(const double2 *) { return 0; }
+__device__ __forceinline__ bool seal_ok(unsigned long long, unsigned long long, int, unsigned) { return true; }
+#else
+// the seal entry: { fold ^ seal_tag, the tag in clear (diagnostics) }
+__device__ __forceinline__ void seal_store(double2 *st, unsigned long long fold, int stream, unsigned third)
+{
+    unsigned long long *p = (unsigned long long *)(st + NVX_STATE_SEAL);
+    __hip_atomic_store(p, fold ^ seal_tag(stream, third), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, ((unsigned long long)(unsigned)stream << 32) | third, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the consumer's side: the seal word is requested together with the block (every lane loads the same word) ...
+__device__ __forceinline__ unsigned long long seal_load(const double2 *st_in)
+{
+    return __hip_atomic_load((const unsigned long long *)(st_in + NVX_STATE_SEAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and judged once the fold over what was loaded is known: true when `got` is the seal of (fold, stream, third)
+__device__ __forceinline__ bool seal_ok(unsigned long long got, unsigned long long fold, int stream, unsigned third)
+{
+    const unsigned long long d = got ^ fold ^ seal_tag(stream, third);
+    return __builtin_amdgcn_readfirstlane((int)((unsigned)d | (unsigned)(d >> 32))) == 0;
+}
+#endif
+
 // One wave's share of the cascade.  lane = 2 * (pair / output index) + component, in stage 0, FIR1, the mixer, FIR2
 // and FIR3 alike.
 template <int NCH>
@@ -196,11 +269,16 @@ struct CascadeWave {
             if (NVX_H1_FIRST.first[i] == i) { h1v[i] = NVX_H1[i]; asm volatile("" : "+v"(h1v[i])); }
     }
 
-    // once per unit
-    __device__ __forceinline__ void begin_unit(unsigned chain_mask, double2 *y3_, size_t row0, size_t cap, int mixbase0, int n_u0, int n_y20, bool emit0)
+    // once per unit: which chains (state_in / state_out need no more than this) ...
+    __device__ __forceinline__ void set_mask(unsigned chain_mask)
     {
         mask = chain_mask;
         chain_of_slot0 = (NCH == 1) ? ((mask & 1u) ? 0 : 1) : 0;
+    }
+    // ... and the rest, once it is known whether the unit starts from carried state or from a pre-roll
+    __device__ __forceinline__ void begin_unit(unsigned chain_mask, double2 *y3_, size_t row0, size_t cap, int mixbase0, int n_u0, int n_y20, bool emit0)
+    {
+        set_mask(chain_mask);
         // mixer table row of this lane: its cross term carries the sign of the 518 chain (I lanes negated) -- or, when the
         // unit's only chain is the 490 one, of that chain (Q lanes negated); see step 4
 #ifdef NVX_MIX_GLOBAL
@@ -214,21 +292,27 @@ struct CascadeWave {
     }
 
     // filter histories from the state block: 36 newest 252 kS/s samples (oldest first), then per chain 46 mixer outputs
-    // and 70 FIR2 outputs
-    __device__ __forceinline__ void state_in(const double2 *st_in)
+    // and 70 FIR2 outputs.  Returns this lane's share of the seal's fold over what it LOADED (nvx_kernels.h).
+    __device__ __forceinline__ unsigned long long state_in(const double2 *st_in)
     {
+        unsigned long long f = 0;
         if (lane < 36) {
             const int v = lane + 4;                    // sample -36+lane = 8*((v>>3) - XH) + (v&7)
-            lds->X[(v & 7) * XS + (v >> 3)] = state_load(st_in + lane);
+            const double2 x = state_load(st_in + lane);
+            f ^= seal_pair<0>(x);
+            lds->X[(v & 7) * XS + (v >> 3)] = x;
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             const double2 *su = st_in + 36 + ch * (46 + 70);
-            if (lane < 46) lds->U[c][lane] = state_load(su + lane);
-            lds->Y2[c][lane] = state_load(su + 46 + lane);
-            if (lane < 6) lds->Y2[c][64 + lane] = state_load(su + 46 + 64 + lane);
+            if (lane < 46) { const double2 u = state_load(su + lane); f ^= (c ? seal_pair<4>(u) : seal_pair<1>(u)); lds->U[c][lane] = u; }
+            const double2 y = state_load(su + 46 + lane);
+            f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
+            lds->Y2[c][lane] = y;
+            if (lane < 6) { const double2 t = state_load(su + 46 + 64 + lane); f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); lds->Y2[c][64 + lane] = t; }
         }
+        return f;
     }
     // ... or silence in front of a pre-roll (independent units)
     __device__ __forceinline__ void state_zero()
@@ -241,20 +325,27 @@ struct CascadeWave {
             for (int i = lane; i < 70 + NVX_PREROLL_Y2; i += 64) lds->Y2[c][i] = zero;
         }
     }
-    __device__ __forceinline__ void state_out(double2 *st)
+    // ... and back; returns this lane's share of the fold over what it STORED
+    __device__ __forceinline__ unsigned long long state_out(double2 *st)
     {
+        unsigned long long f = 0;
         if (lane < 36) {
             const int v = lane + 4;
-            state_store(st + lane, lds->X[(v & 7) * XS + (v >> 3)]);
+            const double2 x = lds->X[(v & 7) * XS + (v >> 3)];
+            f ^= seal_pair<0>(x);
+            state_store(st + lane, x);
         }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             double2 *su = st + 36 + ch * (46 + 70);
-            if (lane < 46) state_store(su + lane, lds->U[c][lane]);
-            state_store(su + 46 + lane, lds->Y2[c][lane]);
-            if (lane < 6) state_store(su + 46 + 64 + lane, lds->Y2[c][64 + lane]);
+            if (lane < 46) { const double2 u = lds->U[c][lane]; f ^= (c ? seal_pair<4>(u) : seal_pair<1>(u)); state_store(su + lane, u); }
+            const double2 y = lds->Y2[c][lane];
+            f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
+            state_store(su + 46 + lane, y);
+            if (lane < 6) { const double2 t = lds->Y2[c][64 + lane]; f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); state_store(su + 46 + 64 + lane, t); }
         }
+        return f;
     }
 
     // One pass: the window holds 256 new samples (entries XH .. XH+31 of every phase) behind its history.

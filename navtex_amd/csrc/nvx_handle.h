@@ -102,8 +102,9 @@ struct nvx_handle {
     nvx_tie_stats *d_ties = nullptr;   // arg-max margin statistics, cumulative since create / reset
     nvx_tie_stats *h_ties = nullptr;   // pinned copy, refreshed behind every launch
     int *d_ctrl = nullptr;             // cascade work queue: counter, status, done[n_streams]
-    int *h_status = nullptr;           // pinned copies of {status, wait polls, units that waited} per result slot
+    int *h_status = nullptr;           // pinned copies of {status, wait polls, units that waited, stale hand-overs repaired} per result slot
     uint64_t wait_polls = 0, wait_units = 0, wait_launches = 0;   // accumulated at collect
+    uint64_t stale_repaired = 0, integrity_failures = 0;          // state-block seals (nvx_kernels.h): hand-overs repaired by a pre-roll, launches failed
     // Per INPUT stream, advanced by every launch the stream takes part in: which cascade state block it reads next
     // (it writes the other) and how many 900 S/s samples its chains have been through since reset.  As long as every
     // launch covered every stream (`diverged` false) all entries are equal and launches need no participant list.

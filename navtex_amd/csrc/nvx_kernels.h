@@ -27,13 +27,35 @@
 #define NVX_PREROLL_PASSES 9
 #define NVX_PREROLL_U 96
 #define NVX_PREROLL_Y2 64
-#define NVX_CASCADE_CTRL_INTS 4           /* [0] work-queue counter, [1] status (non-zero = spin timeout),  */
-                                         /* [2] polls spent waiting for a predecessor, [3] units that waited */
+#define NVX_CASCADE_CTRL_INTS 8           /* [0] work-queue counter, [1] status (1 = spin timeout, 2 = the state a launch   */
+                                         /* inherited failed its integrity word), [2] polls spent waiting for a            */
+                                         /* predecessor, [3] units that waited, [4] hand-overs whose state block failed its */
+                                         /* integrity word and were repaired by a pre-roll (r4), [5..7] unused              */
+#define NVX_STATUS_TIMEOUT 1
+#define NVX_STATUS_INTEGRITY 2
+#define NVX_STATUS_INTS 4                 /* ints [1..4] travel to the host behind every launch                             */
 /* carried FIR state per stream: 36 x {I,Q} @252 kS/s, then per chain 46 mixer
- * outputs and 70 FIR2 outputs, all fp64 pairs; last entry: the third-order stage 0's
- * two blocks of history as four integers (C_I | t_I << 32, C_Q | t_Q << 32)     */
-#define NVX_CASCADE_STATE_ENTRIES (36 + 2 * (46 + 70) + 1)
+ * outputs and 70 FIR2 outputs, all fp64 pairs; entry NVX_STATE_CIC3: the third-order stage 0's
+ * two blocks of history as four integers (C_I | t_I << 32, C_Q | t_Q << 32);
+ * entry NVX_STATE_SEAL (r4): the block's integrity word and its tag in clear (below); padded to
+ * whole 128-byte lines so that the blocks of neighbouring streams share no cache line         */
+#define NVX_STATE_DATA_ENTRIES (36 + 2 * (46 + 70))
+#define NVX_STATE_CIC3 NVX_STATE_DATA_ENTRIES
+#define NVX_STATE_SEAL (NVX_STATE_DATA_ENTRIES + 1)
+#ifndef NVX_CASCADE_STATE_ENTRIES
+#define NVX_CASCADE_STATE_ENTRIES 272
+#endif
 #define NVX_CASCADE_STATE_BYTES   (NVX_CASCADE_STATE_ENTRIES * 16)
+/* The seal.  The state block is the one piece of memory a unit writes and ANOTHER unit -- usually on another XCD, behind
+ * another L2 -- reads within a launch, and the hand-over rests on per-instruction device coherence (sc1) instead of
+ * cache-wide fences: measured behaviour of gfx950, not an architectural guarantee (MI355X_MICROARCH.md).  So a block
+ * carries a 64-bit word over everything the unit stored (every 8-byte pattern rotated by its position and XOR-folded)
+ * mixed with the block's TAG = (stream, the stream's position since reset in thirds of a frame -- which is also the
+ * launch sequence: no two blocks a stream ever writes carry the same tag).  The consumer recomputes it over what it
+ * LOADED; on a mismatch a hand-over unit takes the pre-roll path (bit-identical by construction) and counts the event
+ * (status int [4]); the first unit of a launch, whose predecessor state came through a kernel boundary, reports
+ * NVX_STATUS_INTEGRITY instead.  What the carried state restates: receiver/fir1cpp.C:51-60, receiver/fir2cpp.C:74-83,
+ * receiver/fir3cpp.h:90-95 (the reference keeps it in statics).                                                      */
 #define NVX_DEMOD_DOUBLES (8 + 8 + 8 + 567) /* per slot, contiguous: last 4 IQ, dphi, class sums, |corr| */
 #define NVX_DEMOD_INTS    5
 #define NVX_DI_PHASE       3            /* bit-FSM phase, resets to -1 (waiting)            */
@@ -73,6 +95,8 @@ typedef struct {
     int stage0_order;          /* raw-rate input: 3 = third-order stage 0, anything else = integrate-and-dump     */
     int dynamic_preroll;       /* set by the launcher: a unit whose predecessor is still running pre-rolls instead of waiting */
     int split_from;            /* set by the launcher: frames from this one on are handed out in thirds (n_frames = none) */
+    unsigned third0;           /* position of the launch in its streams, in thirds of a frame since reset (g0 / 96), for the    */
+                               /* state block's tag; with a list every entry carries its own g0                                */
 } nvx_cascade_args;
 
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares
@@ -140,6 +164,7 @@ typedef struct {
     int *queue, *status, *done;/* as nvx_cascade_args; done[n_wide]                                          */
     int independent;           /* set by the launcher: units pre-roll instead of waiting for their predecessor */
     int thirds;                /* set by the launcher (independent units only): a unit is a third of a frame   */
+    unsigned third0;           /* as nvx_cascade_args                                                          */
 } nvx_wideband_args;
 
 #ifdef __cplusplus

@@ -40,7 +40,7 @@
 struct WidebandLds {
     CascadeLds<2> sub[NVX_WB_SUBBANDS_K];
     __attribute__((aligned(16))) unsigned raw[40 + WB_PASS_WORDS];
-    int unit, ok;
+    int unit, ok, bad;
 };
 
 // (the argument block by reference: fields are fetched from the kernarg segment where they are used instead of sitting in
@@ -67,21 +67,25 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         int next = 0;
         if (tid == 0) next = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         next = __builtin_amdgcn_readfirstlane(next);
-        if (wave == 0) L.unit = next;
+        if (wave == 0) { L.unit = next; L.bad = 0; }
         __syncthreads();
         const int u = L.unit;
         if (u >= n_units) break;
         const int part = u / a.n_wide;                  // frame (or third of a frame) of the launch
         const int entry = u - part * a.n_wide;          // position in the launch's list of participants (nvx_kernels.h, nvx_part)
         int w = entry, parity = 0;                      // wideband stream, and which of its state blocks it reads
-        if (a.part) { const unsigned long long e = nvx_load_const_u64(a.part + entry); w = (int)(unsigned)e; parity = (int)(e >> 32); }   // { stream, parity }
+        unsigned third0 = a.third0;                     // where the launch starts in the stream, in thirds of a frame since reset
+        if (a.part) {
+            const unsigned long long e = nvx_load_const_u64(a.part + entry); w = (int)(unsigned)e; parity = (int)(e >> 32);                 // { stream, parity }
+            third0 = (unsigned)(nvx_load_const_u64(&a.part[entry].g0) / NVX_THIRD_Y3);
+        }
         int *const done = a.done + entry;
         const int s = NVX_WB_SUBBANDS_K * w + wave;     // decoded 252 kS/s stream of this wave
         const unsigned mask = a.chain_masks[s];
 
         // independent units: rebuild the histories from the nine passes in front of the unit (above)
-        const bool preroll = a.independent && part > 0;
-        const int pre = preroll ? NVX_PREROLL_PASSES : 0;
+        bool preroll = a.independent && part > 0;
+        int pre = preroll ? NVX_PREROLL_PASSES : 0;
         // the input does not depend on the predecessor: request this wave's piece of the first pass now
         const uint32_t *unit0 = a.raw + ((size_t)w * a.pitch + a.first_sample) + ((size_t)part * unit_passes - (size_t)pre) * WB_PASS_WORDS;
         const u32x4 *src = (const u32x4 *)unit0 + wave * 64 + lane;
@@ -102,7 +106,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
                     __hip_atomic_fetch_add(a.status + 1, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(a.status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (!ok && lane == 0) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up loudly rather than hang
+                if (!ok && lane == 0) __hip_atomic_store(a.status, NVX_STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up loudly rather than hang
                 L.ok = ok;
             }
             __syncthreads();                            // the other waves load the state only behind the poll
@@ -112,22 +116,60 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         // ------------------------------------------------------ state in (sc1 loads)
         double2 *st = (double2 *)((parity ? a.state[0] : a.state[1]) + (size_t)s * NVX_CASCADE_STATE_BYTES);
         const double2 *st_in = (part == 0) ? (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)s * NVX_CASCADE_STATE_BYTES) : st;
+        const uint32_t *hin = (((part == 0) == (parity == 0)) ? a.hist[0] : a.hist[1]) + (size_t)w * 40;
+#ifdef NVX_INJECT_STALE
+        // fault-injection build (tests; see nvx_cascade.hip): every NVX_INJECT_STALE-th hand-over reads the blocks the
+        // stream's PREVIOUS launch left (sub-band 3's wave only, or the halo only, or everything, by turns)
+        if (part > 0 && !preroll && (u % NVX_INJECT_STALE) == 0) {
+            const int how = (u / NVX_INJECT_STALE) % 3;
+            if (how == 0 ? wave == 3 : how == 2) st_in = (const double2 *)((parity ? a.state[1] : a.state[0]) + (size_t)s * NVX_CASCADE_STATE_BYTES);
+            if (how >= 1) hin = (parity ? a.hist[1] : a.hist[0]) + (size_t)w * 40;
+        }
+#endif
+        cw.set_mask(mask);
+        if (!preroll) {
+            NVX_WAVE_LDS_FENCE();
+            const unsigned long long sealed = seal_load(st_in);
+            unsigned long long fold = cw.state_in(st_in);
+            // the 40-sample channeliser halo travels with sub-band 7's block: wave 7 stores it, loads it and seals it
+            if (wave == 7 && lane < 40) {
+                const uint32_t x = __hip_atomic_load(hin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.raw[lane] = x;
+                fold ^= seal_rotc<41>((unsigned long long)x);
+            }
+            // The seal (nvx_kernels.h): what was loaded must be what the predecessor stored, whole and of the right position
+            // (position 0: the zeros of nvx_reset, never stored by a unit)
+            const unsigned third_in = third0 + (unsigned)part * (a.thirds ? 1u : 3u);
+            if (third_in != 0 && !seal_ok(sealed, wave_fold64(fold), s, third_in)) L.bad = 1;
+        }
+        __syncthreads();                                // (every wave's verdict is in; wave 7's halo is in the raw window)
+        if (L.bad) {
+            if (part == 0) {
+                // inherited through a kernel boundary: nothing to fall back on; the launch is reported as failed (and runs
+                // on, so that nobody is left waiting; the host discards its results)
+                if (tid == 0) __hip_atomic_store(a.status, NVX_STATUS_INTEGRITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // a stale or torn hand-over in at least one of the nine blocks: the whole workgroup takes the independent
+                // units' path -- nine passes early from silence, the real samples in front of them as the halo --
+                // bit-identical by construction; counted
+                if (tid == 0) __hip_atomic_fetch_add(a.status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                preroll = true; pre = NVX_PREROLL_PASSES;
+                unit0 -= (size_t)pre * WB_PASS_WORDS;
+                src = (const u32x4 *)unit0 + wave * 64 + lane;
+                pf = __builtin_nontemporal_load(src);
+            }
+        }
         // (a frame starts at mixer index 0, a third at 6720 * third mod 9, and a pre-roll 9 * 64 = 0 mod 9 outputs earlier at
         // the same index; FIR3 outputs of the pre-roll are not written)
         cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * unit_y3, a.y3_cap,
                       a.thirds ? ((part % 3) * (NVX_THIRD_PASSES * 64)) % NVX_MIX_N : 0,
                       preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
         NVX_WAVE_LDS_FENCE();
-        if (!preroll) cw.state_in(st_in); else cw.state_zero();
-        NVX_WAVE_LDS_FENCE();
-        if (wave == 0 && lane < 40) {
-            if (preroll) {
-                L.raw[lane] = unit0[lane - 40];         // the real samples in front of the pre-roll (this launch's own input)
-            } else {
-                const uint32_t *hin = (((part == 0) == (parity == 0)) ? a.hist[0] : a.hist[1]);
-                L.raw[lane] = __hip_atomic_load(hin + (size_t)w * 40 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (preroll) {
+            cw.state_zero();
+            if (wave == 7 && lane < 40) L.raw[lane] = unit0[lane - 40];       // the real samples in front of the pre-roll (this launch's own input)
         }
+        NVX_WAVE_LDS_FENCE();
 
         const int n_pass = pre + unit_passes;
         for (int pass = 0; pass < n_pass; pass++) {
@@ -157,9 +199,14 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         // (independent units: only the stream's last unit of the launch carries state into the next launch)
         NVX_WAVE_LDS_FENCE();
         if (!a.independent || part + 1 == a.n_frames * per_frame) {
-            cw.state_out(st);
-            if (wave == 7 && lane < 40)
-                __hip_atomic_store((parity ? a.hist[0] : a.hist[1]) + (size_t)w * 40 + lane, L.raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long fold = cw.state_out(st);
+            if (wave == 7 && lane < 40) {
+                const uint32_t x = L.raw[lane];
+                __hip_atomic_store((parity ? a.hist[0] : a.hist[1]) + (size_t)w * 40 + lane, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fold ^= seal_rotc<41>((unsigned long long)x);
+            }
+            fold = wave_fold64(fold);
+            if (lane == 0) seal_store(st, fold, s, third0 + (unsigned)(part + 1) * (a.thirds ? 1u : 3u));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains ...
         __syncthreads();                                            // ... before the one lane that signals for all of them

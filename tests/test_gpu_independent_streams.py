@@ -268,6 +268,7 @@ def ragged_case(nv, oracle, seed):
                 p.flush(); flushed = True
         p.flush()
         partial = p.stream_stats(0)[2]
+        stale = p.integrity_stats()[0]
         for s in range(S):
             ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
             if raw:
@@ -278,7 +279,7 @@ def ragged_case(nv, oracle, seed):
                 want = ref.bits(c) if (masks[s] >> c) & 1 else ""
                 assert p.bits(s, c) == want, f"seed {seed}: stream {s} chain {c} (raw {raw}, order {order}, masks {masks}, max_frames {maxf})"
             assert p.stream_stats(s)[1] == F
-    return dict(seed=seed, raw=raw, order=order, streams=S, frames=F, max_frames=maxf, two_chain_kernel=3 in masks, partial_launches=partial)
+    return dict(seed=seed, raw=raw, order=order, streams=S, frames=F, max_frames=maxf, two_chain_kernel=3 in masks, partial_launches=partial, stale_repaired=stale)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
