@@ -20,14 +20,24 @@ Under a launcher (the driver's `python -m torch.distributed.run ... bench.py
 --gpus N`) it is simply one of the ranks.
 
 Every rank checks its OWN shard against the oracle before the timed region (all
-streams at N = 1, a spread sample of them per rank otherwise); the line's
-`parity` is the minimum over ranks, and a failed parity makes the process exit
-with status 3 after printing the line.
+streams at N = 1, a spread sample of them per rank otherwise) AND after it: the
+bits the handle has accumulated over the warm-up and the timed launches -- the
+launches that were measured, with their state carried launch to launch --
+against the oracle fed the same frames as many times (`parity_after_timed`).
+The line's `parity` is the minimum over ranks of both, and a failed parity makes
+the process exit with status 3 after printing the line.
 
 At N = 1 the default line also carries, each outside the headline's timed
-region and each with its own parity sample: `stage0_third_order`, `push_path`
-(host-fed streaming through nvx_push_iq, PCIe-inclusive), `variant_a` (the
-252 kS/s cascade kernel) and `wideband` (the fused channeliser + cascade kernel).
+region and each with its own parity checks (first launch and last):
+`stage0_third_order`, `push_path` (host-fed streaming through nvx_push_iq,
+PCIe-inclusive), `live_latency` (two capture rings fed at the real rate),
+`variant_a` (the 252 kS/s cascade kernel) and `wideband` (the fused channeliser
++ cascade kernel).  A leg that raises is named in `legs_failed` and the process
+exits with status 4 after printing the line (--allow-leg-errors: status 0).
+
+`python bench.py --gpus N --group` runs the same workload through ONE process
+and the library's own multi-GPU object (nvx_group: one handle + host thread per
+device, no collective) instead of one process per GPU.
 
 Prints ONE JSON line on rank 0.
 """
@@ -84,6 +94,13 @@ def parse():
     ap.add_argument("--no-stage0-extra", action="store_true", help="skip the third-order stage 0 measurement beside the headline (N = 1)")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the side legs of the default line (N = 1): variant_a, wideband, push_path (each a few seconds, outside the timed region)")
+    ap.add_argument("--allow-leg-errors", action="store_true", help="a side leg that raises is recorded but does not fail the run (default: exit status 4)")
+    ap.add_argument("--after-timed", type=int, default=64, metavar="N",
+                    help="streams per rank whose accumulated bits are checked against the oracle AFTER the timed region (at least 32 per rank)")
+    ap.add_argument("--cic3-verify", type=int, default=-1, metavar="N",
+                    help="streams of the stage0_third_order leg checked against the oracle (-1 = every stream)")
+    ap.add_argument("--group", action="store_true",
+                    help="one process, nvx_group over devices 0..N-1 (NVX_BENCH_GROUP_DEVICES=0,0 names them explicitly) instead of one process per GPU")
     ap.add_argument("--variant-a", action="store_true",
                     help="reference-native input rate: streams at 252 kS/s, no stage 0 (SURVEY 8d Variant A; fp64-bound, "
                          "reported for completeness -- the headline workload is the default 2.016 MS/s Variant B)")
@@ -187,7 +204,28 @@ def self_launch(args, script=None, argv=None) -> None:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script or Path(__file__).resolve())] + list(sys.argv[1:] if argv is None else argv)
     print("bench.py: launching " + " ".join(cmd[2:8]) + " ...", file=sys.stderr, flush=True)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr goes straight through
+    # the ranks in a session of their own: a SIGTERM / SIGINT / SIGHUP that reaches only this process (a driver's timeout
+    # that is not a process-group kill) is passed on to all of them -- they must not be left holding the GPUs
+    import signal
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)      # stderr goes straight through
+
+    def pass_on(signum, _frame):
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+            try:
+                child.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, pass_on)
+    out, _ = child.communicate()
+
+    class proc:                                   # what the relay below reads
+        stdout, returncode = out, child.returncode
     lines = proc.stdout.splitlines()
     js = [l for l in lines if l.startswith("{")]
     for l in lines:
@@ -198,6 +236,25 @@ def self_launch(args, script=None, argv=None) -> None:
     elif proc.returncode == 0:
         raise SystemExit("bench.py: the ranks printed no JSON line")
     sys.exit(proc.returncode)
+
+
+def traffic_record(S: int, F: int, order: int):
+    """(bytes per launch, where it comes from) from profiles/hbm_traffic.json: one PMC record per (streams, frames, stage-0
+    order) -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes.  A
+    static record of this workload on an earlier box, not a measurement of this run; (None, why) for any other shape."""
+    tf = ROOT / "profiles" / "hbm_traffic.json"
+    have = []
+    try:
+        rec = json.loads(tf.read_text())
+        for e in rec.get("entries", [rec] if "bytes_per_launch" in rec else []):
+            have.append((e.get("streams"), e.get("frames"), e.get("stage0_order", 1)))
+            if e.get("streams") == S and e.get("frames") == F and e.get("stage0_order", 1) == order:
+                return e.get("bytes_per_launch"), ("profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                                   f"not measured by this run; {e.get('source', '')})")
+    except Exception as e:
+        return None, f"null: profiles/hbm_traffic.json unreadable ({type(e).__name__})"
+    return None, (f"null: profiles/hbm_traffic.json holds PMC records of (streams, frames, stage-0 order) {have}, not of ({S}, {F}, {order}) "
+                  "(tools/gpu_scripts/gpu_r04_final.sh collects them)")
 
 
 def cpu_model() -> str:
@@ -298,6 +355,49 @@ def cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv):
 # ----------------------------------------------------------------------------- side legs of the default line (N = 1)
 # Every kernel family and the streaming path get a driver-timed number in the same record as the headline, each with its
 # own parity sample against the oracle, each a few seconds, all OUTSIDE the headline's timed region.
+def leg_stage0_cic3(nv, ob, fullsize, buf, pitch, n_per_stream, S, F, device, ncpu, char_layer, samples_per_step, bytes_per_step, n_verify, n_after, steps=10, warmup=2):
+    """The headline's batch through nvx_config.stage0_order = 3 (the stage the vendor library's closed /8 stands for:
+    receiver/capt_sched.c:412-413).  Checked like the headline: n_verify streams (-1: all) from reset, n_after after the
+    timed launches; traffic from its own PMC record."""
+    p3 = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F, char_layer=char_layer, device=device, stage0_order=3)
+    try:
+        p3.process_resident(buf, pitch, 0, F); p3.fetch()
+        ids3 = fullsize.spread(S, S if n_verify < 0 else min(S, max(1, n_verify)))
+        checked3, bad3, secs3 = fullsize.verify_streams(ob, buf, pitch, n_per_stream, 3, lambda s: p3.bits(s, 0), ids3, ncpu)
+        p3.reset()
+        for _ in range(warmup): p3.process_resident(buf, pitch, 0, F)
+        p3.fetch(); p3.enable_timing(True); p3.kernel_time_stats(0, reset=True); p3.wait_stats(reset=True)
+        t3 = time.perf_counter()
+        for _ in range(steps): p3.process_resident(buf, pitch, 0, F)
+        p3.fetch()
+        e3 = time.perf_counter() - t3
+        c3, n3 = p3.kernel_time_stats(0)
+        c3 /= max(n3, 1)
+        w_polls, w_units, w_launches = p3.wait_stats()
+        ids_after = fullsize.spread(S, min(S, n_after))
+        checked_a, bad_a, secs_a = fullsize.verify_replay(ob, buf, pitch, n_per_stream, 3, lambda s: p3.bits(s, 0), ids_after, ncpu, warmup + steps)
+        stale, failures, _ = p3.integrity_stats()
+        traffic, traffic_source = traffic_record(S, F, 3)
+        achieved = bytes_per_step / (c3 * 1e-3) / 1e9 if c3 > 0 else None
+        if bad3 or bad_a:
+            print(f"PARITY FAILURE (third-order stage 0): first launch {len(bad3)} of {checked3} streams differ (first {bad3[:8]}), "
+                  f"after the timed launches {len(bad_a)} of {checked_a} (first {bad_a[:8]})", file=sys.stderr)
+        return {"what": "the same batch with nvx_config.stage0_order = 3 (22-tap CIC^3, 76 dB of alias rejection at the NAVTEX offsets where the "
+                        "headline's integrate-and-dump has 25: the front end a receiver would ship); not part of the timed region above",
+                "steps": steps, "ms_per_step": round(e3 / steps * 1e3, 3), "value": round(samples_per_step * steps / e3 / 1e6, 1),
+                "cascade_avg_launch_ms": round(c3, 3), "frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade_cic3_1", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                             "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_ms": round(c3, 3), "launches": int(n3),
+                             "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4), "stale_detected": stale,
+                                         "launches_failed_integrity": failures}},
+                "parity": not bad3 and not bad_a, "parity_streams_checked": checked3, "parity_seconds": round(secs3, 1),
+                "parity_after_timed": not bad_a, "parity_after_timed_streams": checked_a, "parity_after_timed_launches": warmup + steps,
+                "parity_after_timed_seconds": round(secs_a, 1)}
+    finally:
+        p3.close()
+
+
 def leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, char_layer, frames=96, steps=5, n_check=64):
     """Reference-native rate (SURVEY 8d Variant A): S streams x `frames` frames at 252 kS/s through nvx_fir_cascade<252k,1>
     (the same bytes per launch as the headline when frames = 96).  fp64-issue-bound: frac is of the 39.3 T no-FMA roof."""
@@ -318,7 +418,11 @@ def leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, char_layer, frames
         el = time.perf_counter() - t0
         c_ms, n_l = p.kernel_time_stats(0); c_ms /= max(n_l, 1)
         w_polls, w_units, w_launches = p.wait_stats()
+        # ... and what the timed launches left behind: 1 + steps launches over the same frames since the reset, state carried
+        checked_a, bad_a, _ = fullsize.verify_replay(ob, buf, n_per, n_per, False, lambda s: p.bits(s, 0), fullsize.spread(S, min(S, n_check)), ncpu, 1 + steps)
+        stale, failures, _ = p.integrity_stats()
         p.close()
+        bad = list(bad) + list(bad_a)
         tops = flops_per_sample(1) * S * n_per / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
         return {"what": f"VARIANT A: {S} streams x {frames} frames at 252 kS/s ({S * n_per * 4 / 1e9:.1f} GB), no stage 0, one chain; not part of the timed region above",
                 "kernel": "nvx_fir_cascade<252k,1>", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
@@ -327,7 +431,9 @@ def leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, char_layer, frames
                              "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(flops_per_sample(1), 2),
                              "hbm_gbs": round(S * n_per * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None},
                 "handoff_units_waited_frac": round(w_units / max(1, w_launches * S * frames), 4),
-                "parity": not bad, "parity_streams_checked": checked}
+                "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
+                "parity": not bad, "parity_streams_checked": checked, "parity_after_timed": not bad_a, "parity_after_timed_streams": checked_a,
+                "parity_after_timed_launches": 1 + steps}
     finally:
         buf.free()
 
@@ -354,7 +460,13 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
         p.fetch()
         el = time.perf_counter() - t0
         c_ms, n_l = p.kernel_time_stats(0); c_ms /= max(n_l, 1)
+        # ... and what the timed launches left behind (1 + steps launches since the reset, channeliser halo and filter state carried)
+        _secs, want_after = ob.replay_wide(part, nw, n_sub, ncpu, 1 + steps)
+        got_after = [p.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
+        ok_after = got_after == want_after and all(len(b) > 0 for b in want_after)
+        stale, failures, _ = p.integrity_stats()
         p.close()
+        ok = ok and ok_after
         sub_samples = 8 * W * n_sub
         tops = flops_per_sample(2) * sub_samples / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
         return {"what": f"WIDEBAND: {W} streams x 2.016 MS/s x {F} frames, 16 NAVTEX carriers each (8 sub-bands x 2 chains) = {16 * W} carriers; "
@@ -367,7 +479,8 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
                              "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(flops_per_sample(2), 2),
                              "hbm_gbs": round(W * n_raw * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None,
                              "note": "only the cascades' fp64 operations are counted; the channeliser's integer work rides on top"},
-                "parity": ok, "parity_carriers_checked": 16 * nw}
+                "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
+                "parity": ok, "parity_carriers_checked": 16 * nw, "parity_after_timed": ok_after, "parity_after_timed_launches": 1 + steps}
     finally:
         raw.free()
 
@@ -404,23 +517,80 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
         for th in ths: th.start()
         for th in ths: th.join()
 
-    one_pass(); p.flush()                                   # from reset state: the checked pass (also the warm-up)
-    _secs, want = ob.bench(host, n_streams, n_per // 8, True, 1, ncpu, want_bits=True)
-    got = [p.bits(s, 0) for s in range(n_streams)]
-    ok = got == want and all(len(b) > 0 for b in want)
+    one_pass(); p.flush()                                   # from reset state: the first checked pass (also the warm-up)
+    _secs, want = ob.replay(host, n_streams, n_per // 8, True, 3, ncpu, 1)
+    got = [[p.bits(s, 0), p.bits(s, 1)] for s in range(n_streams)]
+    ok_first = got == want and all(len(b[0]) > 0 and len(b[1]) > 0 for b in want)
     t0 = time.perf_counter()
     for _ in range(passes):
         one_pass()
     p.flush()
     el = time.perf_counter() - t0
+    # after the LAST pass: both chains of every stream, everything decoded since the reset (1 + passes passes over the same
+    # frames, state carried from pass to pass) == the oracle fed the same
+    _secs, want = ob.replay(host, n_streams, n_per // 8, True, 3, ncpu, 1 + passes)
+    got = [[p.bits(s, 0), p.bits(s, 1)] for s in range(n_streams)]
+    ok_last = got == want and all(len(b[0]) > 0 and len(b[1]) > 0 for b in want)
+    stale, failures, _ = p.integrity_stats()
+    partial = p.stream_stats(0)[2]
     p.close()
+    ok = ok_first and ok_last
     n = passes * n_streams * n_per
     return {"what": f"HOST-FED: {n_streams} streams x 2.016 MS/s pushed from host memory by {n_thr} threads, {fpp} frames at a time (nvx_push_iq -> pinned staging -> "
                     f"hipMemcpyAsync -> kernels -> bits -> character layer), both chains of every stream decoded, {passes} passes over {n_fr} frames; PCIe-inclusive, never `value`",
             "value": round(n / el / 1e6, 1), "unit": "Msamples/s", "h2d_inclusive_gbs": round(4 * n / el / 1e9, 2),
             "x_real_time": round(n / el / nv.RATE_RAW, 1), "x_real_time_per_stream": round(n / el / nv.RATE_RAW / n_streams, 1),
-            "seconds": round(el, 3), "pusher_threads": n_thr, "parity": ok, "parity_streams_checked": n_streams,
-            "parity_note": "bits of the first pass (from reset state) == oracle on every stream; the timed passes repeat the same frames"}
+            "seconds": round(el, 3), "pusher_threads": n_thr, "partial_launches": int(partial),
+            "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
+            "parity": ok, "parity_streams_checked": n_streams, "parity_chains_checked": 2 * n_streams,
+            "parity_after_timed": ok_last, "parity_after_timed_passes": 1 + passes,
+            "parity_note": "both chains of every stream == oracle after the first pass (from reset) AND after the last (everything decoded over "
+                           f"{1 + passes} passes over the same frames, state carried)"}
+
+
+def leg_live_latency(nv, ob, signals, device, seconds=6.0):
+    """The live path's latency (the loop it replaces decodes synchronously per sample and calls add_message inline:
+    receiver/capt_sched.c:484-528 with its 50 ms poll, receiver/nav_b_sm.C:87).  Two capture rings -- one handle fed at
+    252 kS/s as the SDRplay callback delivers it, one at the ADC rate 2.016 MS/s -- each fed by a fake-SDR thread AT THE
+    REAL RATE with jittered packet sizes (tests/fake_sdr.py), both at once.  Latency of frame k = (bits of frame k pollable
+    and its messages delivered) - (entry of the callback that carried frame k's last sample), booked inside the library
+    (nvx_capture_latency).  dropped must be 0 and the bits must equal the oracle's."""
+    from fake_sdr import FakeSdr
+    n_frames = max(4, int(seconds / 0.32))
+    legs, threads = {}, []
+    for name, raw in (("252k", False), ("2016k", True)):
+        rate, frame = (nv.RATE_RAW, nv.FRAME_RAW) if raw else (nv.RATE_IN, nv.FRAME_IN)
+        st, _ = signals.stream_params(nv, 31000 + int(raw), rate, n_phasing=20)
+        iq = nv.synth_host(st, rate, n_frames * frame)
+        p = nv.Pipeline(n_streams=1, raw_rate=raw, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=True, device=device)
+        cap = nv.Capture(p, 0, ring_seconds=2.0)
+        sdr = FakeSdr(cap, iq, rate, frame, seed=5 + int(raw), packet=(1000, 1700) if raw else (150, 420))
+        legs[name] = (p, cap, sdr, iq, raw)
+    for _p, _c, sdr, _iq, _r in legs.values():
+        sdr.start()
+    for _p, _c, sdr, _iq, _r in legs.values():
+        sdr.join()
+    time.sleep(0.12)                                 # the last frame's collect: at most two polls of the consumer (50 ms each)
+    out, ok_all = {}, True
+    for name, (p, cap, sdr, iq, raw) in legs.items():
+        lat = cap.latency()
+        received, dropped, consumed = cap.stats()
+        cap.stop()
+        ref = ob.Pipe(chain_mask=1, charlayer=False)
+        (ref.push_raw if raw else ref.push)(iq)
+        ok = p.bits(0, 0) == ref.bits(0) and len(ref.bits(0)) > 100 and dropped == 0 and lat["frames"] >= n_frames - 1
+        ok_all = ok_all and ok
+        out[name] = {"frames_booked": lat["frames"], "p50_ms": round(lat["p50_ms"], 2), "p99_ms": round(lat["p99_ms"], 2), "max_ms": round(lat["max_ms"], 2),
+                     "dropped": dropped, "received": received, "bits_equal_oracle": bool(p.bits(0, 0) == ref.bits(0)), "bits": len(ref.bits(0)),
+                     "messages": len(p.messages), "fake_sdr_behind_schedule_ms_max": round(sdr.late_ms, 2),
+                     "callbacks_per_s": round(sdr.packets / (n_frames * 0.32), 0)}
+        p.close()
+    return {"what": f"LIVE PATH LATENCY: two capture rings (nvx_capture_callback -> ring -> consumer -> nvx_push_iq -> launch -> nvx_poll), one handle each, fed "
+                    f"at the real rate for {n_frames * 0.32:.1f} s of signal by fake-SDR threads with jittered packet sizes, both at once; latency of a frame = bits "
+                    "pollable and messages delivered - entry of the callback that carried its last sample (booked by the library: nvx_capture_latency)",
+            "streams": out, "frame_seconds": 0.32,
+            "bound_for_a_character_ms": "320 (its frame still filling) + the figures above (launch + collect; 50 ms at worst when no callback wakes the consumer)",
+            "parity": ok_all}
 
 
 def wideband_streams(nv, signals, rank, W, n_phasing=40):
@@ -483,8 +653,9 @@ class Ranks:
         return float(t.item())
 
 
-def finish(line, parity, ranks, rank):
-    """Print the line on rank 0; a failed parity is a failed run (exit status 3) on every rank."""
+def finish(line, parity, ranks, rank, leg_errors=False):
+    """Print the line on rank 0; a failed parity is a failed run (exit status 3) on every rank, a side leg that raised
+    (named in legs_failed) one with status 4."""
     if rank == 0:
         print(json.dumps(line), flush=True)
     if ranks.dist is not None:
@@ -492,6 +663,9 @@ def finish(line, parity, ranks, rank):
         ranks.dist.destroy_process_group()
     if not parity:
         sys.exit(3)
+    if leg_errors:
+        print(f"bench.py: side legs failed: {line.get('legs_failed')} (the line above is complete otherwise; --allow-leg-errors to pass)", file=sys.stderr)
+        sys.exit(4)
 
 
 def run_wideband(args, nv, signals, ranks, rank, world, device, place):
@@ -591,8 +765,127 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     finish(line, parity, ranks, rank)
 
 
+def run_group(args):
+    """`--gpus N --group`: ONE process, the library's own multi-GPU object (nvx_group, header section C': one handle, one host
+    thread bound to the device's NUMA node and one result ring per device; streams shard one contiguous subset per
+    device, no collective -- the independence it rests on: receiver/nav_b_sm.h:92-114, receiver/decoder.h:31-60) on the
+    headline workload per device.  Same JSON line; `ranks.backend` = "group", per-member figures where the multi-process
+    form has per-rank ones.  NVX_BENCH_GROUP_DEVICES=0,0 names the members' devices explicitly (one-GPU rehearsal)."""
+    devs = [int(d) for d in os.environ["NVX_BENCH_GROUP_DEVICES"].split(",")] if os.environ.get("NVX_BENCH_GROUP_DEVICES") else list(range(args.gpus))
+    n = len(devs)
+    have = os.sched_getaffinity(0)
+    threads = int(os.environ.get("NVX_CPU_THREADS", max(1, min(16 * n, len(have)))))
+    import navtex_amd as nv
+    import signals
+    import oracle_binding as ob
+    import fullsize
+    import gc
+    gc.collect(); gc.freeze()
+    if nv.device_count() <= max(devs):
+        raise SystemExit(f"bench.py --group: devices {devs} asked for, {nv.device_count()} present")
+    S, F = args.streams, args.frames
+    order = 3 if args.stage0 == "cic3" else 1
+    oraw = 3 if order == 3 else True
+    n_per_stream = F * nv.FRAME_RAW
+    pitch = n_per_stream + args.pitch_pad
+    samples_per_step = S * n_per_stream                     # per member
+    bytes_per_step = samples_per_step * BYTES_PER_SAMPLE
+    if order != 1:
+        raise SystemExit("bench.py --group runs the headline front end (nvx_group passes cfg through; use the multi-process form for --stage0 cic3)")
+    t0 = time.time()
+    group = nv.Group(devs, n * S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F, char_layer=not args.no_charlayer,
+                     host_threads=max(1, min(16, threads // n)))
+    bufs = []
+    for m, (dev, first, count) in enumerate(group.members):
+        assert count == S
+        b = nv.DeviceBuffer(S * pitch * BYTES_PER_SAMPLE, device=dev)
+        nv.synth_device([signals.stream_params(nv, first + s, nv.RATE_RAW)[0] for s in range(S)], nv.RATE_RAW, n_per_stream, b, pitch)
+        bufs.append(b)
+    t_gen = time.time() - t0
+    ptrs = [b.ptr for b in bufs]
+    views = [group.member_view(m) for m in range(n)]
+
+    def step():
+        group.process_resident(ptrs, pitch, 0, F)
+
+    # ---- parity gate, every member its own shard: first launch from reset ...
+    step(); group.fetch()
+    n_verify = args.verify if args.verify > 0 else (S if n == 1 else 32)
+    checked_m, bad_all, verify_s = [], [], 0.0
+    for m, (dev, first, count) in enumerate(group.members):
+        ids = fullsize.spread(S, n_verify)
+        c, bad, secs = fullsize.verify_streams(ob, bufs[m], pitch, n_per_stream, oraw, lambda s, f=first: group.bits(f + s, 0), ids, threads)
+        checked_m.append(c); bad_all += [first + b for b in bad]; verify_s += secs
+    group.reset()
+    for _ in range(args.warmup):
+        step()
+    group.fetch()
+    for v in views:
+        v.enable_timing(True); v.kernel_time_stats(0, reset=True); v.wait_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    group.fetch()                      # every member's launches done, bits on the host, characters decoded, messages delivered
+    elapsed = time.perf_counter() - t0
+    # ... and after the timed region: what the measured launches produced (state carried launch to launch)
+    loops = args.warmup + args.steps
+    after_m, bad_after, after_s = [], [], 0.0
+    for m, (dev, first, count) in enumerate(group.members):
+        ids = fullsize.spread(S, min(S, max(32, args.after_timed)))
+        c, bad, secs = fullsize.verify_replay(ob, bufs[m], pitch, n_per_stream, oraw, lambda s, f=first: group.bits(f + s, 0), ids, threads, loops)
+        after_m.append(c); bad_after += [first + b for b in bad]; after_s += secs
+    if bad_all or bad_after:
+        print(f"PARITY FAILURE (group): first launch {len(bad_all)} streams differ (first {bad_all[:8]}), after the timed region {len(bad_after)} (first {bad_after[:8]})", file=sys.stderr)
+    parity = not bad_all and not bad_after
+    casc = []
+    stale = failures = 0
+    w_units = w_launches = 0
+    for v in views:
+        ms, nl = v.kernel_time_stats(0); casc.append(ms / max(nl, 1))
+        a, b, _ = v.integrity_stats(); stale += a; failures += b
+        _, wu, wl = v.wait_stats(); w_units += wu; w_launches += wl
+    casc_avg = max(casc)
+    achieved = bytes_per_step / (casc_avg * 1e-3) / 1e9 if casc_avg > 0 else None
+    traffic, traffic_source = traffic_record(S, F, order)
+    line = {
+        "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(n * samples_per_step * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{S} synthetic 170 Hz-shift FSK channels x 2.016 MS/s int16 IQ per GPU, {F} frames ({F * 0.32:.2f} s) resident in HBM "
+                               f"(BASELINE configs[3] per device; x{n} devices behind ONE nvx_group in one process)",
+                   "streams_per_gpu": S, "frames": F, "samples_per_step_per_gpu": samples_per_step, "stage0": "integrate-and-dump /8 (build-owned)",
+                   "chains_per_stream": 1, "parallelism": f"nvx_group: streams sharded over {n} member handles (devices {devs}), one host thread per member, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_ms": round(casc_avg, 3), "per_device": "slowest member; ranks.cascade_avg_launch_ms_per_rank has all",
+                     "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4), "stale_detected": stale, "launches_failed_integrity": failures}},
+        "cpu_baseline": None,
+        "parity": parity, "parity_streams_checked": sum(checked_m), "parity_seconds": round(verify_s, 1),
+        "parity_after_timed": not bad_after, "parity_after_timed_streams": sum(after_m), "parity_after_timed_launches": loops, "parity_after_timed_seconds": round(after_s, 1),
+        "host_threads": threads,
+        "ranks": {"world_size_seen": n, "backend": "group", "note": "one process; a 'rank' here is a member handle of the nvx_group (its own device, host thread and result ring)",
+                  "ms_per_step_per_rank": [round(elapsed / args.steps * 1e3, 3)] * n, "ms_per_step_min": round(elapsed / args.steps * 1e3, 3),
+                  "ms_per_step_max": round(elapsed / args.steps * 1e3, 3),
+                  "parity_streams_checked_per_rank": checked_m, "parity_after_timed_streams_per_rank": after_m,
+                  "cascade_avg_launch_ms_per_rank": [round(c, 3) for c in casc], "device_per_rank": [d for d, _, _ in group.members],
+                  "first_stream_per_rank": [f for _, f, _ in group.members]},
+        "hbm_gbs_whole_job": round(n * bytes_per_step * args.steps / elapsed / 1e9, 1), "gen_seconds": round(t_gen, 1),
+        "messages_delivered": len(group.messages),
+    }
+    group.close()
+    for b in bufs:
+        b.free()
+    print(json.dumps(line), flush=True)
+    if not parity:
+        sys.exit(3)
+
+
 def main():
     args = parse()
+    if args.group:
+        if args.verify == 0:
+            raise SystemExit("--verify 0: an unchecked number is no number")
+        return run_group(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -720,26 +1013,35 @@ def main():
     w_polls, w_units, w_launches = pipe.wait_stats()
     total_bits = sum(pipe.bit_count(s, 0) for s in range(0, S, max(1, S // 64)))
 
+    # ---- parity AFTER the timed region: what the measured launches produced.  The handle was reset before the warm-up;
+    # since then it has run the same F frames (warmup + steps) times, its filter and demodulator state carried from launch
+    # to launch (the reference's statics: receiver/fir1cpp.C:51-60, fir2cpp.C:74-83, fir3cpp.h:90-95, decoder.h:31-60) through
+    # ~(warmup + steps) x S x F unit hand-overs.  The oracle is fed the same frames as many times; every bit must agree.
+    loops = args.warmup + args.steps
+    ids_after = fullsize.spread(S, min(S, max(32, args.after_timed)))
+    checked_after, bad_after, after_s = fullsize.verify_replay(ob, buf, pitch, n_per_stream, oraw, lambda s: pipe.bits(s, 0), ids_after, ncpu, loops)
+    if bad_after:
+        print(f"PARITY FAILURE AFTER THE TIMED REGION (rank {rank}): {len(bad_after)} of {checked_after} streams differ from the CPU oracle "
+              f"after {loops} launches, first {bad_after[:8]}", file=sys.stderr)
+    parity_after = ranks.reduce(0.0 if bad_after else 1.0, "min") > 0.5
+    checked_after_all = int(ranks.reduce(float(checked_after), "sum"))
+    parity = parity and parity_after
+    stale, seal_failures, _ = pipe.integrity_stats()
+    stale_all = int(ranks.reduce(float(stale), "sum"))
+    seal_failures_all = int(ranks.reduce(float(seal_failures), "sum"))
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * samples_per_step * args.steps / elapsed / 1e6
     casc_avg = casc_ms / max(n_l, 1)
     handoff = {"units_waited_frac": round(w_units / max(1, w_launches * S * F), 4),
-               "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)}
+               "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1),
+               # the state blocks' seals (nvx_cascade_integrity_stats), all launches of this handle since create, all ranks:
+               # hand-overs that failed the check and were repaired by a pre-roll / launches whose inherited state failed it
+               "stale_detected": stale_all, "launches_failed_integrity": seal_failures_all,
+               "hand_overs_checked_about": int(w_launches) * S * (F + 1)}       # per stream and launch: F - 1 whole frames + 3 thirds take over from a predecessor
     if raw:
         achieved = bytes_per_step / (casc_avg * 1e-3) / 1e9 if casc_avg > 0 else None
-        traffic, traffic_source = None, None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():
-            try:
-                rec = json.loads(tf.read_text())
-                if rec.get("streams") == S and rec.get("frames") == F and order == 1:
-                    traffic = rec.get("bytes_per_launch")
-                    traffic_source = "profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured by this run)"
-            except Exception:
-                traffic = None
-        if traffic is None:
-            traffic_source = (f"null: profiles/hbm_traffic.json holds the PMC record of 4096 x 12 with the first-order stage 0 only, "
-                              f"not of {S} x {F}, stage0 order {order} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE: tools/gpu_scripts/gpu_r03_final.sh)")
+        traffic, traffic_source = traffic_record(S, F, order)
         roofline = {"bound": "hbm", "kernel": "nvx_fir_cascade<raw,1>" if order == 1 else "nvx_fir_cascade_cic3_1", "achieved": round(achieved, 1) if achieved else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_per_step,
@@ -771,6 +1073,10 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity, "parity_streams_checked": checked_all, "parity_seconds": round(verify_s, 1),
+        "parity_after_timed": parity_after, "parity_after_timed_streams": checked_after_all, "parity_after_timed_launches": loops,
+        "parity_after_timed_seconds": round(after_s, 1),
+        "parity_note": "parity = first launch from reset (every stream at N = 1) AND parity_after_timed: the bits accumulated over the warm-up and "
+                       "the timed launches on a spread sample of streams == the oracle fed the same frames as many times (state carried throughout)",
         "demod": {"near_ties": near_all, "min_relative_margin": margin_all, "timing_evaluations_rank0": int(evals),
                   "span_note": "roofline.demod_span_ms is first-to-last event of the demodulator of launch k, which runs BESIDE the "
                                "cascade of launch k+1 (second stream) and becomes resident as CUs have room: alone it takes ~0.85 ms"},
@@ -780,59 +1086,44 @@ def main():
         "gen_seconds": round(t_gen, 1), "bits_sampled": int(total_bits),
     }
     pipe.close()
-    # ---- beside the headline (N = 1, default front end only): the same batch through the third-order stage 0, the front
-    # end with real alias rejection -- its own parity sample, ten timed steps, outside the headline's clock
-    if raw and order == 1 and world == 1 and not args.no_stage0_extra:
+    legs_failed = []
+
+    def run_leg(name, fn):
+        """A side leg never takes the headline's line down with it -- but it fails the RUN: wrong bits anywhere end the
+        process with status 3, a leg that raises is named in legs_failed and ends it with status 4 (--allow-leg-errors: 0)."""
+        nonlocal parity
+        t_leg = time.perf_counter()
         try:
-            p3 = nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=F,
-                             char_layer=not args.no_charlayer, device=device, stage0_order=3)
-            p3.process_resident(buf, pitch, 0, F); p3.fetch()
-            ids3 = fullsize.spread(S, min(S, 64))
-            checked3, bad3, _ = fullsize.verify_streams(ob, buf, pitch, n_per_stream, 3, lambda s: p3.bits(s, 0), ids3, ncpu)
-            p3.reset()
-            for _ in range(2): p3.process_resident(buf, pitch, 0, F)
-            p3.fetch(); p3.enable_timing(True); p3.kernel_time_stats(0, reset=True)
-            k3 = 10
-            t3 = time.perf_counter()
-            for _ in range(k3): p3.process_resident(buf, pitch, 0, F)
-            p3.fetch()
-            e3 = time.perf_counter() - t3
-            c3, n3 = p3.kernel_time_stats(0)
-            c3 /= max(n3, 1)
-            line["stage0_third_order"] = {
-                "what": "the same batch with nvx_config.stage0_order = 3 (22-tap CIC^3, 76 dB of alias rejection at the NAVTEX "
-                        "offsets where the headline's integrate-and-dump has 25); not part of the timed region above",
-                "steps": k3, "ms_per_step": round(e3 / k3 * 1e3, 3), "value": round(samples_per_step * k3 / e3 / 1e6, 1),
-                "cascade_avg_launch_ms": round(c3, 3), "frac_of_hbm_peak": round(bytes_per_step / (c3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if c3 > 0 else None,
-                "parity": not bad3, "parity_streams_checked": checked3}
-            if bad3:
-                print(f"PARITY FAILURE (third-order stage 0): {len(bad3)} of {checked3} streams differ from the CPU oracle, first {bad3[:8]}", file=sys.stderr)
-                parity = False; line["parity"] = False
-            p3.close()
-        except nv.NvxError as e:
-            line["stage0_third_order"] = {"error": str(e)}
+            rec = fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+            legs_failed.append(name)
+        rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+        line[name] = rec
+        if rec.get("parity") is False:
+            print(f"PARITY FAILURE ({name} leg): GPU bits differ from the CPU oracle", file=sys.stderr)
+            parity = False; line["parity"] = False
+
+    # ---- beside the headline (N = 1, default front end only): the same batch through the third-order stage 0, the front
+    # end with real alias rejection (DESIGN.md 4.2) -- on the same footing as the headline: every stream against the
+    # oracle from reset, a spread sample after its timed launches, its own PMC traffic record
+    if raw and order == 1 and world == 1 and not args.no_stage0_extra:
+        run_leg("stage0_third_order", lambda: leg_stage0_cic3(nv, ob, fullsize, buf, pitch, n_per_stream, S, F, device, ncpu, not args.no_charlayer,
+                                                              samples_per_step, bytes_per_step, args.cic3_verify, max(32, args.after_timed)))
     # ---- side legs (N = 1, default workload only): the streaming path and the other kernel families, driver-timed ----
     if raw and order == 1 and world == 1 and not args.no_legs:
-        def run_leg(name, fn):
-            nonlocal parity
-            t_leg = time.perf_counter()
-            try:
-                rec = fn()
-            except Exception as e:                       # a leg never takes the headline down with it ...
-                rec = {"error": f"{type(e).__name__}: {e}"[:300]}
-            rec["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
-            line[name] = rec
-            if rec.get("parity") is False:               # ... but wrong bits anywhere fail the run
-                print(f"PARITY FAILURE ({name} leg): GPU bits differ from the CPU oracle", file=sys.stderr)
-                parity = False; line["parity"] = False
         run_leg("push_path", lambda: leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=min(64, S), pushers=min(4, ncpu)))
         buf.free()                                       # room for the 252 kS/s batch of the same size
+        run_leg("live_latency", lambda: leg_live_latency(nv, ob, signals, device))
         run_leg("variant_a", lambda: leg_variant_a(nv, ob, fullsize, signals, S, device, ncpu, not args.no_charlayer,
                                                    frames=8 * F if S * 8 * F * nv.FRAME_IN * 4 <= (140 << 30) else F))
         run_leg("wideband", lambda: leg_wideband(nv, ob, signals, max(1, S // 8), F, device, ncpu, not args.no_charlayer))
     else:
         buf.free()
-    finish(line, parity, ranks, rank)
+    line["legs_failed"] = legs_failed
+    finish(line, parity, ranks, rank, leg_errors=bool(legs_failed) and not args.allow_leg_errors)
 
 
 if __name__ == "__main__":

@@ -134,6 +134,15 @@ NVX_API int  nvx_capture_error(nvx_capture *c, uint64_t *full_waits);
  * the stream active again and it continues bit-exactly from its own carried state.                                */
 NVX_API int  nvx_capture_stalled(nvx_capture *c, uint64_t *stall_events);
 NVX_API void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds);
+/* Decode latency of the live path.  The reference decodes synchronously per sample and calls add_message inline
+ * (receiver/capt_sched.c:484-528 with its 50 ms poll, receiver/nav_b_sm.C:87); here a frame (0.32 s) waits for its last
+ * sample, a launch and a collect.  The ring stamps the moment the callback that carried a frame's LAST sample was
+ * entered; when the launch covering the frame has been collected (bits pollable, messages delivered) the latency
+ * collect - arrival is booked.  frames: latencies booked so far; p50 / p99 over the last 8192 of them, max and last in
+ * ms (-1: none yet); reset != 0 clears afterwards.  The bound a receiver can rely on for a character: 0.32 s (its frame
+ * still filling) + what this call reports (launch + collect, a few ms; 50 ms at worst when no callback wakes the
+ * consumer) -- INTEGRATION.md section 1.                                                                             */
+NVX_API int  nvx_capture_latency(nvx_capture *c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset);
 /* debug recording (the reference's debug_mode, capt_sched.c:87-101 PrepWav/EndWav and :516):
  * every span the consumer hands to the pipeline is also appended to a 2-channel 16-bit WAV
  * at the handle's input rate.  filename NULL stops and closes; nvx_capture_stop closes too. */

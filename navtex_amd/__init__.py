@@ -16,7 +16,7 @@ from . import _native as N
 from ._native import (CHAIN_490, CHAIN_518, FRAME_BITS, FRAME_IN, FRAME_RAW, FRAME_Y3, RATE_IN, RATE_RAW,
                       NvxError, lib)
 
-__all__ = ["Pipeline", "Group", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
+__all__ = ["Pipeline", "Group", "Capture", "Sitor", "sitor_encode", "make_stream", "synth_host", "synth_device", "device_count",
            "DeviceBuffer", "channelise", "channelise_time_stats", "Store", "wav_write", "wav_read", "NvxError", "lib",
            "CHAIN_518", "CHAIN_490", "FRAME_BITS", "FRAME_IN", "FRAME_RAW", "FRAME_Y3", "RATE_IN", "RATE_RAW"]
 
@@ -140,7 +140,45 @@ def channelise_time_stats(reset: bool = False):
 
 
 # ------------------------------------------------------------------ pipeline
-class Pipeline:
+class HandleStats:
+    """Instrumentation of one nvx_handle (self._h): what a Pipeline offers about itself and what a Group offers about each
+    of its members (Group.member_view)."""
+    _h = None
+
+    def wait_stats(self, reset: bool = False) -> Tuple[int, int, int]:
+        """(polls, units that waited, launches) of the cascade's unit hand-over since the last reset."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(lib.nvx_cascade_wait_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_wait_stats")
+        return a.value, b.value, c.value
+
+    def integrity_stats(self, reset: bool = False) -> Tuple[int, int, int]:
+        """(hand-overs whose state block failed its seal and were repaired by a pre-roll, launches whose inherited state
+        failed it, launches collected) -- nvx_cascade_integrity_stats; the first two are expected to be 0."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(lib.nvx_cascade_integrity_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_integrity_stats")
+        return a.value, b.value, c.value
+
+    def tie_stats(self) -> Tuple[int, int, float]:
+        """(near ties, evaluations, smallest relative margin) of the bit-timing arg-max since create / reset."""
+        a, b, m = C.c_uint64(), C.c_uint64(), C.c_double()
+        N.check(lib.nvx_demod_tie_stats(self._h, C.byref(a), C.byref(b), C.byref(m)), "nvx_demod_tie_stats")
+        return a.value, b.value, m.value
+
+    def enable_timing(self, on: bool = True) -> None:
+        lib.nvx_enable_timing(self._h, int(on))
+
+    def kernel_ms(self, which: int) -> float:
+        return float(lib.nvx_last_kernel_ms(self._h, which))
+
+    def kernel_time_stats(self, which: int, reset: bool = False):
+        """(sum of HIP-event ms, number of launches) for kernel `which` (0 cascade, 1 demod)."""
+        s, n = C.c_double(), C.c_uint64()
+        N.check(lib.nvx_kernel_time_stats(self._h, which, C.byref(s), C.byref(n), int(reset)), "nvx_kernel_time_stats")
+        return s.value, n.value
+
+
+
+class Pipeline(HandleStats):
     """nvx_handle wrapper: the GPU receive pipeline for n_streams IQ streams."""
 
     def __init__(self, n_streams: int = 1, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
@@ -241,39 +279,8 @@ class Pipeline:
         self._bits.clear()
         self.messages.clear()
 
-    def wait_stats(self, reset: bool = False) -> Tuple[int, int, int]:
-        """(polls, units that waited, launches) of the cascade's unit hand-over since the last reset."""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        N.check(lib.nvx_cascade_wait_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_wait_stats")
-        return a.value, b.value, c.value
-
-    def integrity_stats(self, reset: bool = False) -> Tuple[int, int, int]:
-        """(hand-overs whose state block failed its seal and were repaired by a pre-roll, launches whose inherited state
-        failed it, launches collected) -- nvx_cascade_integrity_stats; the first two are expected to be 0."""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        N.check(lib.nvx_cascade_integrity_stats(self._h, C.byref(a), C.byref(b), C.byref(c), int(reset)), "nvx_cascade_integrity_stats")
-        return a.value, b.value, c.value
-
-    def tie_stats(self) -> Tuple[int, int, float]:
-        """(near ties, evaluations, smallest relative margin) of the bit-timing arg-max since create / reset."""
-        a, b, m = C.c_uint64(), C.c_uint64(), C.c_double()
-        N.check(lib.nvx_demod_tie_stats(self._h, C.byref(a), C.byref(b), C.byref(m)), "nvx_demod_tie_stats")
-        return a.value, b.value, m.value
-
-    def enable_timing(self, on: bool = True) -> None:
-        lib.nvx_enable_timing(self._h, int(on))
-
     def enable_debug(self, on: bool = True) -> None:
         N.check(lib.nvx_enable_debug(self._h, int(on)), "nvx_enable_debug")
-
-    def kernel_ms(self, which: int) -> float:
-        return float(lib.nvx_last_kernel_ms(self._h, which))
-
-    def kernel_time_stats(self, which: int, reset: bool = False):
-        """(sum of HIP-event ms, number of launches) for kernel `which` (0 cascade, 1 demod)."""
-        s, n = C.c_double(), C.c_uint64()
-        N.check(lib.nvx_kernel_time_stats(self._h, which, C.byref(s), C.byref(n), int(reset)), "nvx_kernel_time_stats")
-        return s.value, n.value
 
     STATE_BLOCK_BYTES = 4352
 
@@ -312,6 +319,42 @@ class Pipeline:
         self.close()
 
 
+class Capture:
+    """nvx_capture wrapper: the live-capture ring of header section B' on one stream of a push-mode Pipeline.
+    feed(xi, xq) is the vendor callback (receiver/capt_sched.c:105): planar int16 arrays, copied during the call."""
+
+    def __init__(self, pipe: Pipeline, stream: int = 0, ring_seconds: float = 8.0):
+        c = C.c_void_p()
+        N.check(lib.nvx_capture_start(pipe._h, stream, ring_seconds, C.byref(c)), "nvx_capture_start")
+        self._c, self.pipe, self.stream = c, pipe, stream
+
+    def feed(self, xi: np.ndarray, xq: np.ndarray) -> None:
+        lib.nvx_capture_callback(xi.ctypes.data, xq.ctypes.data, None, xi.shape[0], 0, self._c)
+
+    def stats(self) -> Tuple[int, int, int]:
+        """(samples offered by the producer, dropped on overrun, handed to the pipeline)"""
+        r, d, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib.nvx_capture_stats(self._c, C.byref(r), C.byref(d), C.byref(c))
+        return r.value, d.value, c.value
+
+    def latency(self, reset: bool = False) -> dict:
+        """Decode latency of the frames collected so far (nvx_capture_latency): callback entry of a frame's last sample ->
+        bits pollable and messages delivered, in ms."""
+        n, p50, p99, mx, last = C.c_uint64(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        N.check(lib.nvx_capture_latency(self._c, C.byref(n), C.byref(p50), C.byref(p99), C.byref(mx), C.byref(last), int(reset)), "nvx_capture_latency")
+        return {"frames": n.value, "p50_ms": p50.value, "p99_ms": p99.value, "max_ms": mx.value, "last_ms": last.value}
+
+    def stalled(self) -> Tuple[bool, int]:
+        ev = C.c_uint64()
+        return bool(lib.nvx_capture_stalled(self._c, C.byref(ev))), ev.value
+
+    def stop(self) -> None:
+        """Drain the ring, stop the consumer thread, flush the pipeline."""
+        if self._c:
+            c, self._c = self._c, None
+            N.check(lib.nvx_capture_stop(c), "nvx_capture_stop")
+
+
 class Group:
     """nvx_group wrapper: n_streams sharded over `devices` (one handle + host thread per member, no collective)."""
 
@@ -347,6 +390,14 @@ class Group:
 
     def member_of(self, stream: int) -> int:
         return lib.nvx_group_member_of(self._g, stream)
+
+    def member_view(self, m: int) -> HandleStats:
+        """Instrumentation of member m's handle (kernel timing, hand-over and seal statistics); the group keeps ownership."""
+        h = C.c_void_p()
+        N.check(lib.nvx_group_member(self._g, m, None, None, None, C.byref(h)), "nvx_group_member")
+        v = HandleStats()
+        v._h = h
+        return v
 
     def process_resident(self, ptrs: Sequence[int], pitch: int, first_frame: int, n_frames: int) -> None:
         arr = (C.c_void_p * len(ptrs))(*ptrs)

@@ -60,6 +60,7 @@ def _load() -> C.CDLL:
         "nvx_shim_flush": (i, []), "nvx_shim_bits": (sz, [i, C.c_char_p, sz]),
         "nvx_StreamACallback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
         "nvx_capture_start": (i, [vp, i, C.c_double, C.POINTER(vp)]), "nvx_capture_callback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
+        "nvx_capture_latency": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i]),
         "nvx_capture_stop": (i, [vp]), "nvx_capture_record": (i, [vp, C.c_char_p]), "nvx_fsm_selftest": (i, [u32, i]),
         "nvx_cascade_wait_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]),
         "nvx_debug_cascade_state": (i, [vp, i, vp, sz, i]),

@@ -7,6 +7,7 @@
 // entry point that needs the GPU returns NVX_ERR_NODEV / NVX_ERR_HIP without it
 // (and the void reference-shaped entry points print and abort()).
 #include "nvx_handle.h"
+#include <chrono>
 #include "nvx_fsm.h"
 
 // ------------------------------------------------------------------ errors
@@ -18,6 +19,10 @@ extern "C" void nvx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *nvx_last_error(void) { return g_err; }
+int64_t nvx_now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 extern "C" const char *nvx_version(void) { return "navtex_amd 0.1 (gfx950)"; }
 
 int nvx_select_device(int device)
@@ -127,6 +132,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     h->slots.resize(h->n_slots);
     h->parity.assign(h->n_in, 0);
     h->g0s.assign(h->n_in, 0);
+    h->arrival.assign(h->n_in, nullptr);
     bool any_two = false;
     for (int s = 0; s < h->n_streams; s++) {
         uint8_t m = cfg->chain_masks ? cfg->chain_masks[s] : (uint8_t)cfg->chain_mask;
@@ -209,6 +215,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->cur.assign(h->n_in, 0);
         h->active.assign(h->n_in, 1);
         h->writing.assign(h->n_in, 0);
+        h->pushing.assign(h->n_in, 0);
+        h->last_push_ns.assign(h->n_in, nvx_now_ns());
     }
 #undef CR_TRY
     rc = nvx_reset(h);
@@ -258,6 +266,7 @@ extern "C" int nvx_reset(nvx_handle *h)
     if (!h->fill.empty()) {
         std::fill(h->fill.begin(), h->fill.end(), (size_t)0);
         std::fill(h->active.begin(), h->active.end(), (uint8_t)1);
+        std::fill(h->last_push_ns.begin(), h->last_push_ns.end(), nvx_now_ns());
         // (every copy out of the staging sets has finished: the streams were synchronised above)
         for (int i = 0; i < 2; i++) std::fill(h->set_launch[i].begin(), h->set_launch[i].end(), (uint64_t)0);
     }
@@ -341,21 +350,23 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // sample count and the kernels need no list.  From the first partial launch on (a stream of a push-mode handle had
     // no frame) the streams are on their own clocks: the launch carries a list with each participant's parity and g0.
     const int per_part = h->cfg.wideband ? NVX_WB_SUBBANDS : 1;          // decoded streams per input stream
-    if (part) { h->diverged = true; h->partial_launches++; }
+    // (validated before anything is enqueued or committed; `diverged` and the statistics move only behind the last enqueue)
+    for (int i = 0; part && i < n_part; i++)
+        if (part[i] < 0 || part[i] >= h->n_in || (i > 0 && part[i] <= part[i - 1])) { nvx_set_error("launch list: stream %d out of order or range", part[i]); return NVX_ERR_ARG; }
+    const bool with_list = h->diverged || part != nullptr;
     r.n_part = 0;
     const nvx_part *d_list = nullptr;
-    if (h->diverged) {
+    if (with_list) {
         r.n_part = part ? n_part : h->n_in;
         for (int i = 0; i < r.n_part; i++) {
             const int s = part ? part[i] : i;
-            if (s < 0 || s >= h->n_in || (part && i > 0 && part[i] <= part[i - 1])) { nvx_set_error("launch list: stream %d out of order or range", s); return NVX_ERR_ARG; }
             r.h_part[i] = nvx_part{ s, (int)h->parity[s], h->g0s[s] };
         }
         // (the slot's previous launch has been collected above, so neither copy of its list is still in use)
         HIP_TRY(hipMemcpyAsync(r.d_part, r.h_part, (size_t)r.n_part * sizeof(nvx_part), hipMemcpyHostToDevice, st));
         d_list = r.d_part;
     }
-    const int n_here = h->diverged ? r.n_part : h->n_in;                 // input streams in this launch
+    const int n_here = with_list ? r.n_part : h->n_in;                   // input streams in this launch
     nvx_cascade_args ca{};
     ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
     ca.n_frames = n_frames; ca.n_streams = h->cfg.wideband ? h->n_streams : n_here; ca.chain_masks = h->d_masks;
@@ -421,11 +432,21 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     h->launch_done_valid = true; h->last_launch_stream = st;
     r.pending = true;
     r.n3 = da.n3;
+    r.g0_all = h->g0s[0];
     h->launched++;
     h->last_n3 = da.n3;
     for (int i = 0; i < n_here; i++) {                   // the participants have moved on: other block, n3 more samples
-        const int s = h->diverged ? r.h_part[i].stream : i;
+        const int s = with_list ? r.h_part[i].stream : i;
         h->parity[s] ^= 1; h->g0s[s] += (unsigned long long)da.n3;
+    }
+    if (part) h->partial_launches++;
+    // from the first partial launch on the streams are on their own clocks (every launch carries a list) -- until they
+    // have come together again: same parity, same position
+    h->diverged = with_list;
+    if (h->diverged) {
+        bool together = true;
+        for (int s = 1; s < h->n_in && together; s++) together = h->parity[s] == h->parity[0] && h->g0s[s] == h->g0s[0];
+        if (together) h->diverged = false;
     }
     return NVX_OK;
 }
@@ -444,6 +465,12 @@ int nvx_collect_ready_locked(nvx_handle *h)
         if (rc != NVX_OK) return rc;
     }
     return NVX_OK;
+}
+
+int nvx_launches_in_flight(nvx_handle *h)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    return (int)(h->launched - h->collected);
 }
 
 extern "C" int nvx_poll(nvx_handle *h)
@@ -529,6 +556,18 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
             }
             if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot.load()); return NVX_ERR_STATE; }
             for (int i = 0; i < h->n_slots; i++) if (!h->slots[i].outbox.empty()) deliver_outbox(h, i / 2, h->slots[i]);
+            if (h->n_arrival) {
+                // live path: the frames of this launch are now decoded, pollable and their messages delivered
+                const int64_t now = nvx_now_ns();
+                const int n_frames = r.n3 / NVX_FRAME_Y3, n_str = r.n_part ? r.n_part : h->n_in;
+                for (int k = 0; k < n_str; k++) {
+                    const int s = r.n_part ? r.h_part[k].stream : k;
+                    ArrivalClock *ac = h->arrival[s];
+                    if (!ac) continue;
+                    const uint64_t f0 = (r.n_part ? r.h_part[k].g0 : r.g0_all) / NVX_FRAME_Y3;
+                    for (int f = 0; f < n_frames; f++) ac->book(f0 + (uint64_t)f, now);
+                }
+            }
             r.pending = false;
         }
         h->collected++;

@@ -1,5 +1,6 @@
 // nvx_capture.cpp -- live-capture ring (header section B').
 #include "nvx_handle.h"
+#include <chrono>
 
 // ===========================================================================
 // live-capture ring (section B'): capt_sched.c's producer / ring / consumer
@@ -23,26 +24,36 @@ struct nvx_capture {
     std::atomic<int> stall_ms{ 2000 };
     std::atomic<int> silent{ 0 };
     std::atomic<uint64_t> stall_events{ 0 };
+    ArrivalClock clock;                         // frame arrival stamps and booked decode latencies (nvx_handle.h)
+    size_t frame_in = 0;                        // complex samples per frame at the handle's input rate
     std::mutex rec_mu; nvx_wav *rec = nullptr;  // debug recording of what the consumer hands on (capt_sched.c:87-101, 516)
     std::thread worker;
 };
 
 static void capture_consumer(nvx_capture *c)
 {
+    // the stall clock runs from the first sample handed on (a radio may take seconds to deliver its first one: SDR
+    // initialisation is not a stall) and does not count time the ring was paused
     auto last_progress = std::chrono::steady_clock::now();
+    bool seen_any = false;
     for (;;) {
         {
+            // The reference polls every 50 ms (capt_sched.c:486); this consumer is woken by the callback, and falls back to
+            // the 50 ms.  While a launch is in flight it looks again after 2 ms, so that the results of the LAST frame before
+            // the radio goes quiet (no callback left to wake it) reach the sink within milliseconds, not within a poll interval.
+            const int wait_ms = nvx_launches_in_flight(c->h) ? 2 : 50;
             std::unique_lock<std::mutex> lk(c->cv_mu);
-            c->cv.wait_for(lk, std::chrono::milliseconds(50), [&] {     // the reference polls every 50 ms (capt_sched.c:486)
+            c->cv.wait_for(lk, std::chrono::milliseconds(wait_ms), [&] {
                 return c->stop.load() || (!c->paused.load() && c->head.load() != c->tail.load());
             });
         }
         // results of launches that have finished meanwhile: bits and messages reach the user within a poll interval even
         // when no further launch follows (the last message before the band goes quiet); never waits for the GPU
         if (int rc = nvx_poll(c->h); rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }
-        const bool idle = c->paused.load() || c->head.load() == c->tail.load();
+        if (c->paused.load()) last_progress = std::chrono::steady_clock::now();
+        const bool idle = c->head.load() == c->tail.load();
         const int limit = c->stall_ms.load();
-        if (idle && !c->stop.load() && !c->silent.load() && limit > 0 &&
+        if (idle && seen_any && !c->paused.load() && !c->stop.load() && !c->silent.load() && limit > 0 &&
             std::chrono::steady_clock::now() - last_progress > std::chrono::milliseconds(limit)) {
             if (nvx_stream_set_active(c->h, c->stream, 0) == NVX_OK) { c->silent.store(1); c->stall_events.fetch_add(1); }
         }
@@ -71,7 +82,7 @@ static void capture_consumer(nvx_capture *c)
             t += n;
             c->tail.store(t);
             c->consumed.fetch_add(n);
-            if (n) { last_progress = std::chrono::steady_clock::now(); c->silent.store(0); }     // (the push made the stream active again)
+            if (n) { last_progress = std::chrono::steady_clock::now(); seen_any = true; c->silent.store(0); }     // (the push made the stream active again)
             if (backoff) break;
         }
         if (backoff) {
@@ -95,6 +106,15 @@ extern "C" int nvx_capture_start(nvx_handle *h, int stream, double ring_seconds,
     c->cap = (size_t)(ring_seconds * rate);                              // capt_sched.c:443: rate * seconds
     if (c->cap < 16) c->cap = 16;
     c->ring.assign(2 * c->cap, 0);
+    c->frame_in = h->frame_in;
+    {
+        // latency bookkeeping: the handle's frame count of this stream now = frame 0 of the capture (whole frames; samples
+        // already staged for the stream would shift the capture's frames by less than one)
+        std::lock_guard<std::mutex> lk(h->mu);
+        c->clock.base = h->g0s[stream] / NVX_FRAME_Y3 + (h->fill.empty() ? 0 : h->fill[stream] / h->frame_in);
+        if (!h->arrival[stream]) h->n_arrival++;
+        h->arrival[stream] = &c->clock;
+    }
     c->worker = std::thread(capture_consumer, c);
     *out = c;
     return NVX_OK;
@@ -105,6 +125,7 @@ extern "C" void nvx_capture_callback(short *xi, short *xq, void *params, unsigne
     (void)params; (void)reset;
     nvx_capture *c = (nvx_capture *)cbContext;
     if (!c || !xi || !xq) return;
+    const int64_t t_enter = nvx_now_ns();
     std::lock_guard<std::mutex> lk(c->prod_mu);
     c->received.fetch_add(numSamples);
     const uint64_t hd = c->head.load();
@@ -117,7 +138,28 @@ extern "C" void nvx_capture_callback(short *xi, short *xq, void *params, unsigne
         c->ring[2 * at + 1] = xq[k];
     }
     c->head.store(hd + n);
+    // frames whose last sample this call carried (counted in samples the ring took: what the handle will see)
+    for (uint64_t f = hd / c->frame_in; f < (hd + n) / c->frame_in; f++) c->clock.stamp(f, t_enter);
     c->cv.notify_one();
+}
+
+extern "C" int nvx_capture_latency(nvx_capture *c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset)
+{
+    if (!c) return NVX_ERR_ARG;
+    std::vector<float> v;
+    {
+        std::lock_guard<std::mutex> lk(c->clock.mu);
+        v = c->clock.lat_ms;
+        if (frames) *frames = c->clock.booked;
+        if (max_ms) *max_ms = c->clock.max_ms;
+        if (last_ms) *last_ms = c->clock.last_ms;
+        if (reset) { c->clock.lat_ms.clear(); c->clock.booked = 0; c->clock.max_ms = 0.f; c->clock.last_ms = 0.f; }
+    }
+    std::sort(v.begin(), v.end());
+    auto pct = [&](double q) { return v.empty() ? -1.0 : (double)v[std::min(v.size() - 1, (size_t)(q * (double)v.size()))]; };
+    if (p50_ms) *p50_ms = pct(0.50);
+    if (p99_ms) *p99_ms = pct(0.99);
+    return NVX_OK;
 }
 
 extern "C" int nvx_capture_record(nvx_capture *c, const char *filename)
@@ -180,6 +222,10 @@ extern "C" int nvx_capture_stop(nvx_capture *c)
     int rc = c->error.load();
     if (rc == NVX_OK) rc = nvx_flush(c->h);
     if (c->rec) nvx_wav_close(c->rec);                                   // EndWav, capt_sched.c:98-101
+    {
+        std::lock_guard<std::mutex> lk(c->h->mu);                        // no collect books into the clock any more
+        if (c->h->arrival[c->stream] == &c->clock) { c->h->arrival[c->stream] = nullptr; c->h->n_arrival--; }
+    }
     delete c;
     return rc;
 }

@@ -57,12 +57,47 @@ struct Result {                        // one in-flight launch's bit output
     nvx_part *h_part = nullptr, *d_part = nullptr;
     int n_part = 0;
     int n3 = 0;                        // 900 S/s samples per chain in the launch
+    unsigned long long g0_all = 0;     // no list: the 900 S/s sample count every stream had when the launch went out
     hipEvent_t copied = nullptr;       // push mode: the launch's host-to-device copies have left the staging sets
     hipEvent_t done = nullptr;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
     bool timed = false;
     bool pending = false;
 };
+
+// Decode latency of the live path (r4).  The reference decodes synchronously, sample by sample, and calls add_message
+// inline (receiver/capt_sched.c:484-528, receiver/nav_b_sm.C:87); here a frame waits for its last sample, a launch and a
+// collect.  A capture ring stamps the moment the vendor callback that carried a frame's LAST sample was entered; when
+// the launch that covers the frame has been collected -- bits pollable, messages delivered -- the handle books
+// (collect time - arrival) for the frame.  Owned by the capture ring, registered with the handle per input stream.
+struct ArrivalClock {
+    static const int RING = 512;             // frames between callback and collect (a ring of seconds holds a few dozen)
+    static const int KEEP = 8192;            // latencies kept for the percentiles (a receiver runs for weeks)
+    std::mutex mu;
+    int64_t t_ns[RING];
+    uint64_t stamped = 0;                    // capture frames stamped so far: frame f of the capture, f < stamped
+    uint64_t base = 0;                       // the handle's frame count of the stream when the capture started
+    std::vector<float> lat_ms;               // the last KEEP booked latencies (ring once full)
+    uint64_t booked = 0;
+    float max_ms = 0.f, last_ms = 0.f;
+    void stamp(uint64_t frame, int64_t ns)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        t_ns[frame % RING] = ns;
+        if (frame + 1 > stamped) stamped = frame + 1;
+    }
+    void book(uint64_t handle_frame, int64_t now_ns)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (handle_frame < base) return;
+        const uint64_t f = handle_frame - base;
+        if (f >= stamped || stamped - f > RING) return;       // not one of this capture's frames, or stamped too long ago
+        const float ms = (float)((double)(now_ns - t_ns[f % RING]) * 1e-6);
+        if (lat_ms.size() < (size_t)KEEP) lat_ms.push_back(ms); else lat_ms[booked % KEEP] = ms;
+        booked++; last_ms = ms; if (ms > max_ms) max_ms = ms;
+    }
+};
+int64_t nvx_now_ns();
 
 struct nvx_handle {
     nvx_config cfg{};
@@ -113,6 +148,8 @@ struct nvx_handle {
     bool diverged = false;
     uint64_t partial_launches = 0;     // launches that covered only some of the streams, since create
     Result res[RESULT_SLOTS];
+    std::vector<ArrivalClock *> arrival;   // per input stream: the capture ring's clock, or nullptr (guarded by mu)
+    int n_arrival = 0;
     uint64_t launched = 0, collected = 0;
     int last_n3 = 0;
     // timing
@@ -145,6 +182,8 @@ struct nvx_handle {
     // writers: how many in all.  Whoever wants to move fill / cur (a launch out of the staging sets, flush, reset) raises
     // quiesce, waits on wr_cv for writers == 0 (no new copy starts meanwhile) and lowers it again.
     std::vector<uint8_t> writing;
+    std::vector<uint8_t> pushing;              // stream s has a push call in progress (one pusher per stream, for the whole call)
+    std::vector<int64_t> last_push_ns;         // when stream s last delivered samples (nvx_now_ns; create / reset count as a delivery)
     int writers = 0, quiesce = 0;
     std::condition_variable wr_cv;
 };
@@ -176,6 +215,8 @@ bool nvx_wb_fused();
 int nvx_collect_locked(nvx_handle *h, uint64_t upto = UINT64_MAX);
 // ... the same for every launched block that has ALREADY finished: never waits (handle locked)
 int nvx_collect_ready_locked(nvx_handle *h);
+// launches whose results have not been taken in yet (takes the handle's lock)
+int nvx_launches_in_flight(nvx_handle *h);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries
 const uint32_t *nvx_fsm_table_host();
 

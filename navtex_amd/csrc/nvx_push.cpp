@@ -11,13 +11,22 @@
 // own carried state; the late one joins a later launch and continues bit-exactly from where it stopped.
 static int n_whole_frames(const nvx_handle *h, int s) { return (int)(h->fill[s] / h->frame_in); }
 
-// every active stream has a whole frame (and there is at least one active stream)
+// A stream fed directly through nvx_push_* has no capture ring to declare it silent: one that has delivered nothing for
+// this long is not waited for either (the same 2 s as the ring's default stall timeout), so that the healthy streams keep
+// launching frame by frame instead of only when their staging is full.  Its next push counts again at once.
+#define NVX_PUSH_STALL_NS 2000000000ll
+
+// every active stream has a whole frame (and there is at least one that is waited for and has one)
 static bool lockstep_ready(const nvx_handle *h)
 {
     bool any = false;
+    const int64_t now = nvx_now_ns();
     for (int s = 0; s < h->n_in; s++) {
         if (!h->active[s]) continue;
-        if (h->fill[s] < h->frame_in) return false;
+        if (h->fill[s] < h->frame_in) {
+            if (now - h->last_push_ns[s] > NVX_PUSH_STALL_NS) continue;       // gone quiet: not waited for
+            return false;
+        }
         any = true;
     }
     return any;
@@ -90,8 +99,15 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
-    h->wr_cv.wait(lk, [&] { return !h->writing[stream]; });       // a stream has one writer at a time
-    if (n) h->active[stream] = 1;                    // a stream that delivers is (again) one the others wait for
+    // a stream has ONE pusher at a time, for the whole call (the lock is released while this one waits for a launch or
+    // copies a large chunk: a second pusher of the same stream must not interleave its chunks with this one's)
+    h->wr_cv.wait(lk, [&] { return !h->pushing[stream]; });
+    h->pushing[stream] = 1;
+    struct Release {
+        nvx_handle *h; int stream;
+        ~Release() { h->pushing[stream] = 0; h->wr_cv.notify_all(); }       // (the handle is locked on every path out of here)
+    } release{ h, stream };
+    if (n) { h->active[stream] = 1; h->last_push_ns[stream] = nvx_now_ns(); }    // a stream that delivers is (again) one the others wait for
     size_t done = 0;
     // a launch out of the staging sets: with every unlocked copy committed, and only if `still` holds afterwards (another
     // thread may have launched while this one waited)

@@ -50,7 +50,13 @@ static void keeper_loop(nvx_handle *h)
 {
     std::unique_lock<std::mutex> lk(g_keeper_mu);
     while (!g_keeper_stop.load()) {
-        g_keeper_cv.wait_for(lk, std::chrono::milliseconds(50));
+        // 50 ms, the reference's own poll interval (capt_sched.c:486); 2 ms while a launch is in flight, so that its results
+        // reach add_message within milliseconds even when no further sample arrives
+        lk.unlock();
+        const int wait_ms = nvx_launches_in_flight(h) ? 2 : 50;
+        lk.lock();
+        if (g_keeper_stop.load()) break;
+        g_keeper_cv.wait_for(lk, std::chrono::milliseconds(wait_ms));
         if (g_keeper_stop.load()) break;
         lk.unlock();
         if (nvx_poll(h) != NVX_OK) { fprintf(stderr, "navtex_amd: housekeeping: %s\n", nvx_last_error()); lk.lock(); break; }

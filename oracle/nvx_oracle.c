@@ -823,3 +823,73 @@ double nvxo_bench_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthre
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* TEST INFRASTRUCTURE, as everything in this file.  What a benchmark loop over a resident batch computes: the same `n`
+ * samples of every stream pushed `loops` times into ONE pipe per stream, the carried state (FIR histories: fir1cpp.C:51-60,
+ * fir2cpp.C:74-83, fir3cpp.h:90-95; decoder: decoder.h:31-60) running through from repeat to repeat.  bits_out:
+ * [nstreams][chains][cap], chains = 2 when chain_mask = 3 (chain 0 then chain 1), else the one chain of the mask.        */
+double nvxo_replay(const int16_t *iq, size_t nstreams, size_t n, int raw, int chain_mask, int nthreads, int loops, char *bits_out, size_t cap)
+{
+    struct timespec t0, t1;
+    const size_t stride = (raw ? n * NVXO_D0 : n) * 2;
+    const int nch = chain_mask == 3 ? 2 : 1;
+    if (nthreads < 1) nthreads = 1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (long s = 0; s < (long)nstreams; s++) {
+        nvxo_pipe *p = nvxo_pipe_new(chain_mask, 518, 490, NULL, NULL);
+        nvxo_pipe_set_charlayer(p, 0);
+        if (raw) nvxo_pipe_set_stage0(p, raw == 3 ? 3 : 1);
+        for (int k = 0; k < loops; k++) {
+            if (raw) nvxo_pipe_push_raw(p, iq + (size_t)s * stride, n);
+            else     nvxo_pipe_push(p, iq + (size_t)s * stride, n);
+        }
+        for (int c = 0; c < nch && bits_out; c++) {
+            size_t nb; const char *b = nvxo_pipe_bits(p, nch == 2 ? c : ((chain_mask & 1) ? 0 : 1), &nb);
+            char *dst = bits_out + ((size_t)s * nch + c) * cap;
+            if (nb >= cap) nb = cap - 1;
+            memcpy(dst, b, nb); dst[nb] = 0;
+        }
+        nvxo_pipe_free(p);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ... and the same for wideband streams: raw is [nwide][n_out * 8] at 2.016 MS/s, the channeliser's 40-sample history
+ * carried from repeat to repeat like the pipes' state; bits_out: [nwide * 8][2][cap].                                   */
+double nvxo_replay_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthreads, int loops, char *bits_out, size_t cap)
+{
+    struct timespec t0, t1;
+    if (nthreads < 1) nthreads = 1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (long w = 0; w < (long)nwide; w++) {
+        const int16_t *in = raw + (size_t)w * n_out * 16;
+        int16_t *sub = malloc(8 * n_out * 2 * sizeof(int16_t));
+        int16_t hist[80];
+        nvxo_pipe *p[8];
+        for (int k = 0; k < 8; k++) { p[k] = nvxo_pipe_new(3, 518, 490, NULL, NULL); nvxo_pipe_set_charlayer(p[k], 0); }
+        for (int l = 0; l < loops; l++) {
+            nvxo_channelise(in, n_out, l ? hist : NULL, sub);
+            memcpy(hist, in + (n_out * 8 - 40) * 2, sizeof hist);          /* the last 40 raw samples, oldest first */
+            for (int k = 0; k < 8; k++) nvxo_pipe_push(p[k], sub + (size_t)k * n_out * 2, n_out);
+        }
+        for (int k = 0; k < 8; k++) {
+            for (int c = 0; c < 2 && bits_out; c++) {
+                size_t nb; const char *b = nvxo_pipe_bits(p[k], c, &nb);
+                char *dst = bits_out + ((size_t)(w * 8 + k) * 2 + c) * cap;
+                if (nb >= cap) nb = cap - 1;
+                memcpy(dst, b, nb); dst[nb] = 0;
+            }
+            nvxo_pipe_free(p[k]);
+        }
+        free(sub);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

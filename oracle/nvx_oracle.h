@@ -131,6 +131,13 @@ double nvxo_bench(const int16_t *iq, size_t nstreams, size_t n, int raw, int cha
 double nvxo_bench_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthreads, int repeat, char *bits_out, size_t cap);
 int    nvxo_max_threads(void);
 
+
+/* What a benchmark loop over a resident batch computes: the same samples pushed `loops` times into ONE pipe per stream,
+ * state carried from repeat to repeat.  bits_out: [nstreams][chains][cap] (chains = 2 for chain_mask 3, else 1);
+ * nvxo_replay_wide: [nwide * 8][2][cap], channeliser history carried too.  Return the seconds spent.                 */
+double nvxo_replay(const int16_t *iq, size_t nstreams, size_t n, int raw, int chain_mask, int nthreads, int loops, char *bits_out, size_t cap);
+double nvxo_replay_wide(const int16_t *raw, size_t nwide, size_t n_out, int nthreads, int loops, char *bits_out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,30 @@ def verify_streams(ob, buf, pitch: int, n_samples: int, raw: bool, gpu_bits: Cal
     return checked, bad, time.perf_counter() - t0
 
 
+def verify_replay(ob, buf, pitch: int, n_samples: int, raw, gpu_bits: Callable[[int], object], streams: Sequence[int], ncpu: int,
+                  loops: int, chain_mask: int = 1, chunk: int = 64) -> Tuple[int, List[int], float]:
+    """What a benchmark loop leaves behind: gpu_bits(s) -- everything the handle has decoded on stream s since its reset,
+    after `loops` launches over the SAME n_samples of the resident batch -- against the oracle fed those samples `loops`
+    times through one pipe per stream (state carried from repeat to repeat, as the handle carries it from launch to
+    launch).  chain_mask 3: gpu_bits(s) returns [chain 0, chain 1].  Returns (checked, differing streams, seconds)."""
+    t0 = time.perf_counter()
+    n252 = n_samples // 8 if raw else n_samples
+    bad: List[int] = []
+    streams = list(streams)
+    for c0 in range(0, len(streams), chunk):
+        ids = streams[c0:c0 + chunk]
+        sample = np.empty((len(ids), n_samples, 2), dtype=np.int16)
+        for k, s in enumerate(ids):
+            sample[k] = buf.download(n_samples * 4, offset=s * pitch * 4, dtype=np.int16).reshape(-1, 2)
+        _secs, want = ob.replay(sample, len(ids), n252, raw, chain_mask, ncpu, loops)
+        for k, s in enumerate(ids):
+            got = gpu_bits(s)
+            w = want[k]
+            if got != w or not (w if isinstance(w, str) else all(w)):
+                bad.append(s)
+    return len(streams), bad, time.perf_counter() - t0
+
+
 def spread(n_total: int, n_pick: int) -> List[int]:
     """n_pick stream indices spread over 0..n_total-1, first and last included."""
     if n_pick >= n_total:

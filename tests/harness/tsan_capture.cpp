@@ -44,6 +44,8 @@ int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, 
     *accepted = take;
     return full ? NVX_ERR_FULL : NVX_OK;
 }
+int64_t nvx_now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int nvx_launches_in_flight(nvx_handle *) { static std::atomic<unsigned> n{ 0 }; return (int)(++n % 3 == 0); }    // now and then "a launch is in flight": the short wait
 extern "C" int nvx_flush(nvx_handle *) { return NVX_OK; }
 extern "C" int nvx_poll(nvx_handle *) { return NVX_OK; }                 // the consumer's every-wake "take in what has finished"
 // the consumer's silent-radio report (nvx_capture.cpp: stall timeout) lands here
@@ -54,6 +56,7 @@ int main(int argc, char **argv)
 {
     nvx_handle h;                                  // only cfg / n_in are read by the capture code
     h.cfg.push_mode = 1; h.cfg.raw_rate = 0; h.cfg.wideband = 0; h.n_in = 1;
+    h.frame_in = 4096; h.g0s.assign(1, 0); h.arrival.assign(1, nullptr);      // what nvx_capture_start reads for its frame clock
     nvx_capture *cap = nullptr;
     if (nvx_capture_start(&h, 0, 0.02, &cap) != NVX_OK) return 2;      // 5040-sample ring: wraps constantly
     if (argc > 1 && nvx_capture_record(cap, argv[1]) != NVX_OK) return 3;
@@ -78,10 +81,20 @@ int main(int argc, char **argv)
             if ((x >> 8) % 7 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
     });
+    uint64_t booked_frames = 0;
     std::thread meddler([&] {                     // pauses and resumes the consumer: provokes overruns
+        uint64_t next = 0;
         for (int i = 0; i < 12; i++) {
             nvx_capture_pause(cap, 1); std::this_thread::sleep_for(std::chrono::milliseconds(2));
             nvx_capture_pause(cap, 0); std::this_thread::sleep_for(std::chrono::milliseconds(3));
+            // ... and plays the handle's collect: books the frames stamped so far (the frame clock the callback writes), and
+            // reads the statistics, while the callback keeps stamping
+            {
+                std::lock_guard<std::mutex> lk(h.mu);
+                if (ArrivalClock *ac = h.arrival[0]) for (int k = 0; k < 8; k++) ac->book(next++, nvx_now_ns());
+            }
+            double p50, p99, mx, last;
+            if (nvx_capture_latency(cap, &booked_frames, &p50, &p99, &mx, &last, 0) != NVX_OK) g_bad++;
         }
     });
     vendor.join(); meddler.join();
@@ -94,6 +107,7 @@ int main(int argc, char **argv)
     printf("received %llu dropped %llu pushed %llu bad %llu full_waits %llu\n", (unsigned long long)rx, (unsigned long long)dropped,
            (unsigned long long)pushed, (unsigned long long)g_bad.load(), (unsigned long long)full_waits);
     if (full_waits == 0) return 7;                                     // the back-pressure path really ran
+    if (booked_frames == 0 || h.arrival[0] != nullptr) return 8;       // latencies were booked; the clock was unregistered at stop
     if (rx != total || pushed + dropped != total || g_bad.load() != 0) return 5;
     printf("tsan capture ok\n");
     return 0;

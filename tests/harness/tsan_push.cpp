@@ -11,6 +11,7 @@
 
 extern "C" void nvx_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 bool nvx_wb_fused() { return true; }
+int64_t nvx_now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int nvx_collect_locked(nvx_handle *, uint64_t) { return NVX_OK; }
 
 // ---- the "device": d_in is host memory here; a launch appends what it was given to the stream's received sequence
@@ -52,7 +53,7 @@ int main()
     std::vector<uint32_t> stage[2], din((size_t)S * max_frames * h.frame_in);
     for (int i = 0; i < 2; i++) { stage[i].assign((size_t)S * h.stage_cap, 0); h.h_stage[i] = stage[i].data(); h.set_launch[i].assign(S, 0); }
     h.d_in = din.data();
-    h.fill.assign(S, 0); h.cur.assign(S, 0); h.active.assign(S, 1); h.writing.assign(S, 0);
+    h.fill.assign(S, 0); h.cur.assign(S, 0); h.active.assign(S, 1); h.writing.assign(S, 0); h.pushing.assign(S, 0); h.last_push_ns.assign(S, nvx_now_ns());
     h.parity.assign(S, 0); h.g0s.assign(S, 0);
     g_got.assign(S, {});
 

@@ -45,6 +45,8 @@ for name, res, args in [
     ("nvxo_pipe_set_charlayer", None, [_vp, _i]),
     ("nvxo_bench", C.c_double, [_vp, _sz, _sz, _i, _i, _i, _i, _vp, _sz]), ("nvxo_max_threads", _i, []),
     ("nvxo_bench_wide", C.c_double, [_vp, _sz, _sz, _i, _i, _vp, _sz]),
+    ("nvxo_replay", C.c_double, [_vp, _sz, _sz, _i, _i, _i, _i, _vp, _sz]),
+    ("nvxo_replay_wide", C.c_double, [_vp, _sz, _sz, _i, _i, _vp, _sz]),
 ]:
     fn = getattr(L, name)
     fn.restype, fn.argtypes = res, args
@@ -227,6 +229,28 @@ def bench_wide(raw: np.ndarray, nwide: int, n_out: int, nthreads: int, repeat: i
     secs = L.nvxo_bench_wide(_p(raw), nwide, n_out, nthreads, repeat, buf, cap)
     bits = [buf.raw[i * cap:(i + 1) * cap].split(b"\0")[0].decode("ascii") for i in range(nwide * 16)] if want_bits else None
     return secs, bits
+
+
+def replay(iq: np.ndarray, nstreams: int, n: int, raw, chain_mask: int, nthreads: int, loops: int):
+    """What a benchmark loop over a resident batch computes: iq ([nstreams, n*(8 if raw else 1), 2] int16) pushed `loops` times
+    into ONE pipe per stream, state carried from repeat to repeat.  Returns (seconds, bits): one string per stream, or
+    [chain 0, chain 1] per stream when chain_mask is 3."""
+    iq = np.ascontiguousarray(iq, dtype=np.int16)
+    nch = 2 if chain_mask == 3 else 1
+    cap = loops * (n // 2520) + 64
+    buf = C.create_string_buffer(nstreams * nch * cap)
+    secs = L.nvxo_replay(_p(iq), nstreams, n, int(raw), chain_mask, nthreads, loops, buf, cap)
+    flat = [buf.raw[i * cap:(i + 1) * cap].split(b"\0")[0].decode("ascii") for i in range(nstreams * nch)]
+    return secs, (flat if nch == 1 else [flat[2 * s:2 * s + 2] for s in range(nstreams)])
+
+
+def replay_wide(raw: np.ndarray, nwide: int, n_out: int, nthreads: int, loops: int):
+    """The same for wideband streams ([nwide, n_out*8, 2] int16): (seconds, bits[nwide*16]) with index (w*8 + k)*2 + chain."""
+    raw = np.ascontiguousarray(raw, dtype=np.int16)
+    cap = loops * (n_out // 2520) + 64
+    buf = C.create_string_buffer(nwide * 16 * cap)
+    secs = L.nvxo_replay_wide(_p(raw), nwide, n_out, nthreads, loops, buf, cap)
+    return secs, [buf.raw[i * cap:(i + 1) * cap].split(b"\0")[0].decode("ascii") for i in range(nwide * 16)]
 
 
 # --------------------------------------------------- compiled reference seams

@@ -1,0 +1,193 @@
+"""bench.py's self-verification (round 4): the oracle's replay (what a benchmark loop over a resident batch computes),
+the per-(shape, front end) traffic record, legs that fail loudly -- on CPU -- and, on the GPU box, the real script at test
+size: parity checked AFTER the timed region, the seals' counters in the line, the nvx_group mode, the live path's
+latency against the bound INTEGRATION.md states."""
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import signals
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def _line(out):
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_replay_is_one_pipe_fed_the_same_samples_again(nv, oracle):
+    """nvxo_replay(loops) == one pipe per stream pushed with the sample `loops` times (state carried), both chains, both
+    input rates, both stage-0 forms; nvxo_replay_wide carries the channeliser's 40-sample history the same way."""
+    n = 3 * nv.FRAME_IN
+    iqs = []
+    for s in range(2):
+        car = [dict(freq_hz=f, bits=nv.sitor_encode(signals.stream_text(60 + s), 8), bit_offset=101 * (s + 1), phase0=s * 31337, amplitude=6000) for f in (14000, -14000)]
+        iqs.append(nv.synth_host(nv.make_stream(car, seed=60 + s, noise_amp=1500), nv.RATE_IN, n))
+    iq = np.stack(iqs)
+    _s, got = oracle.replay(iq, 2, n, False, 3, 2, 3)
+    for k in range(2):
+        p = oracle.Pipe(chain_mask=3, charlayer=False)
+        for _ in range(3):
+            p.push(iq[k])
+        assert got[k] == [p.bits(0), p.bits(1)] and len(p.bits(0)) > 200 and len(p.bits(1)) > 200
+    # raw rate, one chain, both stage-0 forms
+    st, _ = signals.stream_params(nv, 61, nv.RATE_RAW)
+    rawiq = nv.synth_host(st, nv.RATE_RAW, 2 * nv.FRAME_RAW)[None]
+    for order in (1, 3):
+        _s, got = oracle.replay(rawiq, 1, 2 * nv.FRAME_IN, 3 if order == 3 else True, 1, 1, 4)
+        p = oracle.Pipe(chain_mask=1, charlayer=False); p.set_stage0(order)
+        for _ in range(4):
+            p.push_raw(rawiq[0])
+        assert got[0] == p.bits(0) and len(got[0]) > 150, order
+    # wideband
+    rng = np.random.default_rng(3)
+    wide = rng.integers(-9000, 9000, size=(1, 2 * nv.FRAME_RAW, 2), dtype=np.int16)
+    _s, got = oracle.replay_wide(wide, 1, 2 * nv.FRAME_IN, 2, 3)
+    sub = oracle.channelise(np.concatenate([wide[0]] * 3))
+    for k in range(8):
+        p = oracle.Pipe(chain_mask=3, charlayer=False); p.push(sub[k])
+        assert got[2 * k] == p.bits(0) and got[2 * k + 1] == p.bits(1) and len(p.bits(0)) > 100, k
+
+
+def test_traffic_record_is_per_shape_and_front_end():
+    import bench
+    b1, src1 = bench.traffic_record(4096, 12, 1)
+    assert b1 and 1.0 <= b1 / (4 * 4096 * 12 * 645120) < 1.03 and "static" in src1
+    none, why = bench.traffic_record(64, 12, 1)
+    assert none is None and why.startswith("null") and "(64, 12, 1)" in why
+    rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+    for e in rec["entries"]:                                    # every entry is what bench.py would return for its shape
+        assert bench.traffic_record(e["streams"], e["frames"], e.get("stage0_order", 1))[0] == e["bytes_per_launch"]
+        assert e["bytes_per_launch"] == int(e["fetch_size_kb"] * 1024 * 2 + e["write_size_kb"] * 1024)
+
+
+def test_a_leg_that_raises_fails_the_run_with_status_4(tmp_path, capsys):
+    """finish(): parity false -> status 3 (wins), a leg that raised -> status 4 after the line is printed, else 0."""
+    import bench
+
+    class NoRanks:
+        dist = None
+    line = {"value": 1, "legs_failed": ["variant_a"]}
+    with pytest.raises(SystemExit) as e:
+        bench.finish(line, True, NoRanks(), 0, leg_errors=True)
+    assert e.value.code == 4 and json.loads(capsys.readouterr().out.strip())["legs_failed"] == ["variant_a"]
+    with pytest.raises(SystemExit) as e:
+        bench.finish(line, False, NoRanks(), 0, leg_errors=True)
+    assert e.value.code == 3
+    bench.finish(line, True, NoRanks(), 0, leg_errors=False)      # returns
+
+
+def test_self_launch_passes_a_signal_on_to_its_ranks(tmp_path):
+    """`bench.py --gpus N` killed by SIGTERM (a driver timeout that is not a process-group kill) must take the ranks
+    with it: they run in a session of their own and get the signal passed on."""
+    import signal
+    worker = tmp_path / "worker.py"
+    worker.write_text("import os, sys, time\nopen(sys.argv[1] + '/pid' + os.environ.get('RANK', 'x'), 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import sys, argparse\nsys.path.insert(0, {str(ROOT)!r})\nimport bench\n"
+                   f"bench.self_launch(argparse.Namespace(gpus=2), script={str(worker)!r}, argv=[{str(tmp_path)!r}])\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.Popen([sys.executable, str(drv)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t0 = time.time()
+    while time.time() - t0 < 60 and not ((tmp_path / "pid0").exists() and (tmp_path / "pid1").exists()):
+        time.sleep(0.2)
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_bench_checks_the_timed_launches_and_reports_the_seals():
+    """The real bench.py at test size with every side leg: parity gated before AND after the timed region, in the headline
+    and in each leg; the seals' counters in the line (0 stale hand-overs); no leg failed; exit status 0."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--streams", "256", "--frames", "4", "--steps", "5", "--warmup", "2", "--cpu-streams", "8"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _line(out)
+    assert rec["parity"] is True and rec["parity_after_timed"] is True and rec["parity_after_timed_streams"] >= 32 and rec["parity_after_timed_launches"] == 7
+    assert rec["roofline"]["handoff"]["stale_detected"] == 0 and rec["roofline"]["handoff"]["launches_failed_integrity"] == 0
+    assert rec["legs_failed"] == []
+    c3 = rec["stage0_third_order"]
+    assert c3["parity"] is True and c3["parity_streams_checked"] == 256 and c3["parity_after_timed"] is True and c3["roofline"]["handoff"]["stale_detected"] == 0
+    for leg in ("push_path", "variant_a", "wideband"):
+        assert rec[leg]["parity"] is True and rec[leg]["parity_after_timed"] is True and rec[leg]["handoff"]["stale_detected"] == 0, leg
+    assert rec["push_path"]["parity_chains_checked"] == 2 * rec["push_path"]["parity_streams_checked"]
+    live = rec["live_latency"]
+    assert live["parity"] is True
+    for name in ("252k", "2016k"):
+        st = live["streams"][name]
+        assert st["dropped"] == 0 and st["bits_equal_oracle"] and 0 < st["p50_ms"] <= st["p99_ms"] <= st["max_ms"] < 150.0, st
+
+
+@pytest.mark.gpu
+def test_bench_group_mode_two_members_on_one_gpu():
+    """`bench.py --gpus 2 --group`: one process, nvx_group over two member handles (both on device 0 here: the first
+    multi-GPU box runs the same command without the override), same JSON line, parity before and after the timed region
+    per member."""
+    env = dict(os.environ, NVX_BENCH_GROUP_DEVICES="0,0")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--group", "--streams", "96", "--frames", "6", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = _line(out)
+    assert rec["n_gpus"] == 2 and rec["parity"] is True and rec["parity_after_timed"] is True
+    r = rec["ranks"]
+    assert r["backend"] == "group" and r["world_size_seen"] == 2 and r["device_per_rank"] == [0, 0] and r["first_stream_per_rank"] == [0, 96]
+    assert r["parity_streams_checked_per_rank"] == [32, 32] and r["parity_after_timed_streams_per_rank"] == [64, 64]
+    assert len(r["cascade_avg_launch_ms_per_rank"]) == 2 and all(c > 0 for c in r["cascade_avg_launch_ms_per_rank"])
+    assert rec["roofline"]["handoff"]["stale_detected"] == 0 and rec["value"] > 0
+
+
+@pytest.mark.gpu
+def test_nnnn_reaches_add_message_within_the_documented_bound(nv, oracle):
+    """a character appears at most 0.32 s (its frame still filling) + launch + collect after
+    the per-sample reference (receiver/capt_sched.c:484-528, receiver/nav_b_sm.C:87) would have produced it; the collect
+    follows the launch within one wake of the ring's consumer -- the next callback, 50 ms at worst.  A message is fed at
+    the real rate through a capture ring; the frame in which it completes is found with the oracle (the first whole-frame
+    prefix that yields the message); the sink must have it within 150 ms of that frame's last sample entering the
+    callback, i.e. within 0.32 s + 150 ms of any of its samples."""
+    from fake_sdr import FakeSdr
+    text = "ZCZC LA07\nLATENCY TEST 1234\nNNNN\n"
+    st, _ = signals.stream_params(nv, 777, nv.RATE_IN, n_phasing=12, text=text)
+    n_frames = 26
+    iq = nv.synth_host(st, nv.RATE_IN, n_frames * nv.FRAME_IN)
+    k_done = None
+    ref = oracle.Pipe(chain_mask=1, charlayer=True)
+    for k in range(n_frames):                                # the first frame with which the oracle completes the message
+        ref.push(iq[k * nv.FRAME_IN:(k + 1) * nv.FRAME_IN])
+        if ref.messages:
+            k_done = k + 1; break
+    assert k_done is not None and ref.messages[0][1] == "LA07", "the oracle never completed the message"
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=True) as p:
+        cap = nv.Capture(p, 0, ring_seconds=2.0)
+        sdr = FakeSdr(cap, iq, nv.RATE_IN, nv.FRAME_IN, seed=9, packet=(150, 420))
+        sdr.start()
+        t_msg = None
+        while sdr.is_alive() or t_msg is None:
+            if p.messages and t_msg is None:
+                t_msg = time.monotonic()
+            if not sdr.is_alive() and t_msg is None and time.monotonic() - sdr.frame_done_at[-1] > 1.0:
+                break
+            time.sleep(0.0005)
+        sdr.join()
+        lat = cap.latency()
+        r, d, c = cap.stats()
+        cap.stop()
+        assert d == 0 and sdr.late_ms < 50.0, (d, sdr.late_ms)
+        assert t_msg is not None and p.messages[0][1:] == ref.messages[0]
+        t_frame = sdr.frame_done_at[k_done - 1]              # entry of the callback that carried the deciding frame's last sample
+        delay_ms = (t_msg - t_frame) * 1e3
+        assert -1.0 <= delay_ms <= 150.0, f"message {delay_ms:.1f} ms after its frame was complete (frame {k_done} of {n_frames})"
+        assert lat["frames"] >= n_frames - 2 and lat["max_ms"] < 150.0, lat

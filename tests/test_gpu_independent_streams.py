@@ -395,3 +395,62 @@ def test_ragged_cases_with_the_hand_over_forms_forced(nv, tmp_path):
         assert last.startswith("20 cases identical to the oracle"), last
         kinds = last[last.index("{"):]
         assert kinds.count("(") == 6, (env, last)                 # all six (rate, stage-0 order, chains) list kernels were met
+
+
+def test_two_pushers_of_one_stream_take_turns_call_by_call(nv, oracle):
+    """a push call is atomic with respect to other pushes of the SAME stream -- a second pusher waits for the whole
+    call, also while the first one waits for a launch or copies a large chunk without the handle's lock.  Two threads push
+    one multi-frame chunk each into stream 0 at the same moment: the stream must read X then Y or Y then X, never a mix."""
+    import threading
+    F = 5
+    st, _ = signals.stream_params(nv, 8080, nv.RATE_RAW)
+    xy = nv.synth_host(st, nv.RATE_RAW, 2 * F * nv.FRAME_RAW)
+    x, y = xy[: F * nv.FRAME_RAW], xy[F * nv.FRAME_RAW:]
+    wants = []
+    for order in ((x, y), (y, x)):
+        ref = oracle.Pipe(chain_mask=1, charlayer=False)
+        ref.push_raw(order[0]); ref.push_raw(order[1])
+        wants.append(ref.bits(0))
+    assert wants[0] != wants[1]
+    seen = set()
+    for rep in range(6):
+        with nv.Pipeline(n_streams=2, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=False) as p:
+            p.set_active(1, False)
+            go = threading.Barrier(2)
+            def pusher(chunk):
+                go.wait(); p.push(0, chunk)
+            ths = [threading.Thread(target=pusher, args=(c,)) for c in (x, y)]
+            for t in ths: t.start()
+            for t in ths: t.join()
+            p.flush()
+            got = p.bits(0, 0)
+            assert got in wants, f"round {rep}: the two pushes were interleaved"
+            seen.add(wants.index(got))
+    assert seen                                                 # (either order is legitimate; usually both occur)
+
+
+def test_a_stream_fed_directly_that_goes_quiet_is_not_waited_for(nv, oracle):
+    """a stream fed through nvx_push_iq (no capture ring to declare it silent) that stops delivering must not
+    keep the others at one launch per FULL staging buffer: after 2 s without a push it is no longer waited for, and the
+    healthy stream's frames go out one by one again.  It rejoins bit-exactly."""
+    import time
+    F, maxf = 14, 8
+    iqs = [nv.synth_host(signals.stream_params(nv, 8200 + s, nv.RATE_IN)[0], nv.RATE_IN, F * nv.FRAME_IN) for s in range(2)]
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=maxf, push_mode=True, char_layer=False) as p:
+        for s in range(2):
+            p.push(s, iqs[s][: 2 * nv.FRAME_IN])                # both deliver two frames: lock-step launches
+        assert p.stream_stats(0)[1] == 2 and p.stream_stats(1)[1] == 2
+        p.push(0, iqs[0][2 * nv.FRAME_IN: 4 * nv.FRAME_IN])     # stream 1 has gone quiet; stream 0 waits for it at first ...
+        assert p.stream_stats(0)[1] == 2
+        time.sleep(2.2)
+        p.push(0, iqs[0][4 * nv.FRAME_IN: 5 * nv.FRAME_IN])     # ... and after 2 s no longer: everything staged goes out
+        assert p.stream_stats(0)[1] == 5, "the healthy stream must not wait for a full staging buffer"
+        p.push(0, iqs[0][5 * nv.FRAME_IN: 6 * nv.FRAME_IN])
+        assert p.stream_stats(0)[1] == 6                        # frame by frame now (staging holds 9)
+        p.push(1, iqs[1][2 * nv.FRAME_IN:])                     # the quiet one comes back with all it has
+        p.push(0, iqs[0][6 * nv.FRAME_IN:])
+        p.flush()
+        for s in range(2):
+            ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(iqs[s])
+            assert p.bits(s, 0) == ref.bits(0) and len(ref.bits(0)) > 300, s
+        assert p.integrity_stats()[:2] == (0, 0)
