@@ -64,11 +64,14 @@ BYTES_PER_SAMPLE = 4           # int16 I + int16 Q, each read from HBM exactly o
 FP64_NOFMA_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12            # 39.3
 # fp64 operations per 252 kS/s complex input sample: FIR1 37 taps x 2 components x (mul + add) / 4, then per chain
 # mixer 6 / 4, FIR2 47 x 2 x 2 / 28, FIR3 71 x 2 x 2 / 280   
-FLOP_FIR1, FLOP_PER_CHAIN = 37.0, 6 / 4 + 47 * 4 / 28 + 71 * 4 / 280
+FLOP_FIR1, FLOP_FIR3, FLOP_PER_CHAIN = 37.0, 71 * 4 / 280, 6 / 4 + 47 * 4 / 28 + 71 * 4 / 280
 
 
-def flops_per_sample(chains: int) -> float:
-    return FLOP_FIR1 + chains * FLOP_PER_CHAIN
+def flops_per_sample(chains: int, fir3_inside: bool = True) -> float:
+    """fp64 operations a cascade kernel executes per 252 kS/s input sample; fir3_inside False: the fused wideband kernel, whose
+    waves end at FIR2 (FIR3 is nvx_fir3, a kernel of its own whose time is reported beside it) -- its roof fraction
+    counts what IT executes, not the path's total."""
+    return FLOP_FIR1 + chains * (FLOP_PER_CHAIN - (0.0 if fir3_inside else FLOP_FIR3))
 
 
 def parse():
@@ -355,6 +358,14 @@ def cpu_baseline_leg(ob, buf, pitch, n_per_stream, F, S, oraw, ncpu, args, nv):
 # ----------------------------------------------------------------------------- side legs of the default line (N = 1)
 # Every kernel family and the streaming path get a driver-timed number in the same record as the headline, each with its
 # own parity sample against the oracle, each a few seconds, all OUTSIDE the headline's timed region.
+def fir3_avg_ms(pipe, launches) -> float:
+    """Average HIP-event time of nvx_fir3 per launch (wideband handles; 0 elsewhere, and with an older library in an A/B run)."""
+    try:
+        return pipe.kernel_time_stats(2)[0] / max(launches, 1)
+    except Exception:
+        return 0.0
+
+
 def leg_stage0_cic3(nv, ob, fullsize, buf, pitch, n_per_stream, S, F, device, ncpu, char_layer, samples_per_step, bytes_per_step, n_verify, n_after, steps=10, warmup=2):
     """The headline's batch through nvx_config.stage0_order = 3 (the stage the vendor library's closed /8 stands for:
     receiver/capt_sched.c:412-413).  Checked like the headline: n_verify streams (-1: all) from reset, n_after after the
@@ -460,6 +471,7 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
         p.fetch()
         el = time.perf_counter() - t0
         c_ms, n_l = p.kernel_time_stats(0); c_ms /= max(n_l, 1)
+        f3_ms = fir3_avg_ms(p, n_l)
         # ... and what the timed launches left behind (1 + steps launches since the reset, channeliser halo and filter state carried)
         _secs, want_after = ob.replay_wide(part, nw, n_sub, ncpu, 1 + steps)
         got_after = [p.bits(s, c) for s in range(8 * nw) for c in (0, 1)]
@@ -468,17 +480,20 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
         p.close()
         ok = ok and ok_after
         sub_samples = 8 * W * n_sub
-        tops = flops_per_sample(2) * sub_samples / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
+        fused = os.environ.get("NVX_WB_FUSED", "1") != "0"
+        fps = flops_per_sample(2, fir3_inside=not fused)
+        tops = fps * sub_samples / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
         return {"what": f"WIDEBAND: {W} streams x 2.016 MS/s x {F} frames, 16 NAVTEX carriers each (8 sub-bands x 2 chains) = {16 * W} carriers; "
-                        "channeliser + two-chain cascades in one kernel; not part of the timed region above",
+                        "channeliser + two-chain cascades (FIR1, mixers, FIR2) in one kernel, FIR3 in nvx_fir3 beside the next launch; not part of the timed region above",
                 "kernel": "nvx_wideband_fused" if os.environ.get("NVX_WB_FUSED", "1") != "0" else "nvx_channelise + nvx_fir_cascade<252k,2>",
                 "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "value": round(W * n_raw * steps / el / 1e6, 1),
                 "carrier_equivalent_msamples_per_s": round(16 * W * n_raw * steps / el / 1e6, 1),
-                "kernel_avg_launch_ms": round(c_ms, 3),
+                "kernel_avg_launch_ms": round(c_ms, 3), "fir3_avg_launch_ms": round(f3_ms, 3),
                 "roofline": {"bound": "fp64_valu", "achieved": round(tops, 2) if tops else None, "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s",
-                             "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(flops_per_sample(2), 2),
+                             "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(fps, 2),
                              "hbm_gbs": round(W * n_raw * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None,
-                             "note": "only the cascades' fp64 operations are counted; the channeliser's integer work rides on top"},
+                             "note": "the fp64 operations the kernel itself executes (FIR1, mixers, FIR2 of both chains; since r4 FIR3 -- 2.03 of the path's "
+                                     "55.46 operations per sample -- is nvx_fir3, fir3_avg_launch_ms, beside the next launch); the channeliser's integer work rides on top"},
                 "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
                 "parity": ok, "parity_carriers_checked": 16 * nw, "parity_after_timed": ok_after, "parity_after_timed_launches": 1 + steps}
     finally:
@@ -732,8 +747,10 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     w_polls, w_units, w_launches = pipe.wait_stats()
     casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
     fused = n_c == 0                                # the fused kernel has no separate channeliser launch
+    f3_avg = fir3_avg_ms(pipe, n_l)
     sub_samples = 8 * W * n_sub
-    tops = flops_per_sample(2) * sub_samples / (casc_avg * 1e-3) / 1e12 if casc_avg else None
+    fps = flops_per_sample(2, fir3_inside=not fused)  # the fused kernel's waves end at FIR2: nvx_fir3 does the rest
+    tops = fps * sub_samples / (casc_avg * 1e-3) / 1e12 if casc_avg else None
     line = {
         "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(world * W * n_raw * args.steps / elapsed / 1e6, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -744,10 +761,11 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                    "parallelism": f"wideband streams sharded {world} ways, no collective"},
         "carriers_decoded": 16 * W * world,
         "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
-        "roofline": {"bound": "fp64_valu", "kernel": "nvx_wideband_fused (channeliser + 8 x two-chain cascade)" if fused else "nvx_fir_cascade<252k,2>",
+        "roofline": {"bound": "fp64_valu", "kernel": "nvx_wideband_fused (channeliser + 8 x two-chain cascade up to FIR2; FIR3 = nvx_fir3)" if fused else "nvx_fir_cascade<252k,2>",
+                     "fir3_avg_launch_ms": round(f3_avg, 3),
                      "achieved": round(tops, 2) if tops else None,
                      "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
-                     "traffic": None, "flop_per_sample": round(flops_per_sample(2), 2), "samples_per_launch": sub_samples,
+                     "traffic": None, "flop_per_sample": round(fps, 2), "samples_per_launch": sub_samples,
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
                      "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F * (1 if n_c == 0 else 8)), 4),
                                  "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)},

@@ -256,7 +256,9 @@ NVX_API size_t nvx_bit_count(nvx_handle *h, int stream, int chain);
 /* ---- instrumentation -------------------------------------------------------
  * HIP-event durations (ms) of the kernels of the most recent
  * nvx_process_resident / push launch, measured on the launch stream:
- * which = 0 FIR cascade, 1 demodulator.  Valid after a synchronise.          */
+ * which = 0 FIR cascade (wideband handles: the fused channeliser + cascade
+ * kernel), 1 demodulator, 2 FIR3 as its own kernel (wideband handles, whose
+ * fused kernel ends at FIR2; 0 otherwise).  Valid after a synchronise.       */
 NVX_API float nvx_last_kernel_ms(nvx_handle *h, int which);
 NVX_API void  nvx_enable_timing(nvx_handle *h, int enabled);
 /* sum of the event durations (ms) and number of timed launches collected since

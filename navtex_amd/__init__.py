@@ -171,7 +171,7 @@ class HandleStats:
         return float(lib.nvx_last_kernel_ms(self._h, which))
 
     def kernel_time_stats(self, which: int, reset: bool = False):
-        """(sum of HIP-event ms, number of launches) for kernel `which` (0 cascade, 1 demod)."""
+        """(sum of HIP-event ms, number of launches) for kernel `which` (0 cascade, 1 demodulator, 2 nvx_fir3 of a wideband handle)."""
         s, n = C.c_double(), C.c_uint64()
         N.check(lib.nvx_kernel_time_stats(self._h, which, C.byref(s), C.byref(n), int(reset)), "nvx_kernel_time_stats")
         return s.value, n.value

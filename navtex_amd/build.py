@@ -24,7 +24,7 @@ LIB = PKG / "libnavtex_amd.so"
 ARCH = "gfx950"
 
 C_SOURCES = ["nvx_sitor.c", "nvx_wav.c", "nvx_synth_host.c", "nvx_store.c"]
-HIP_SOURCES = ["nvx_cascade.hip", "nvx_demod.hip", "nvx_channelise.hip", "nvx_wideband_fused.hip", "nvx_synth.hip"]
+HIP_SOURCES = ["nvx_cascade.hip", "nvx_fir3.hip", "nvx_demod.hip", "nvx_channelise.hip", "nvx_wideband_fused.hip", "nvx_synth.hip"]
 CXX_SOURCES = ["nvx_api.cpp", "nvx_push.cpp", "nvx_shim.cpp", "nvx_capture.cpp", "nvx_wideband.cpp", "nvx_synth_dev.cpp", "nvx_fsm_host.cpp", "nvx_group.cpp"]
 
 # -ffp-contract=off is part of the numerical contract: FIR products and sums are

@@ -77,6 +77,7 @@ static void free_handle(nvx_handle *h)
         if (h->sub_free[i]) hipEventDestroy(h->sub_free[i]);
         if (h->in_ready[i]) hipEventDestroy(h->in_ready[i]);
     }
+    hipFree(h->d_y2[0]); hipFree(h->d_y2[1]); hipFree(h->d_y2row);
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate[0]); hipFree(h->d_cstate[1]); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
     if (h->fsm_done) hipEventDestroy(h->fsm_done);
@@ -91,7 +92,7 @@ static void free_handle(nvx_handle *h)
         hipFree(r.d_part); if (r.h_part) hipHostFree(r.h_part);
         if (r.copied) hipEventDestroy(r.copied);
         if (r.done) hipEventDestroy(r.done);
-        for (int i = 0; i < 6; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
+        for (int i = 0; i < 8; i++) if (r.ev[i]) hipEventDestroy(r.ev[i]);
     }
     for (int i = 0; i < 2; i++) {
         if (h->h_stage[i]) hipHostFree(h->h_stage[i]);
@@ -173,6 +174,15 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_cstate[i], (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
+    if (cfg->wideband && nvx_wb_fused()) {
+        // the fused wideband kernel's waves end at FIR2: a row of 9 kS/s fp64 pairs per ACTIVE chain, two buffers (nvx_kernels.h)
+        std::vector<int> rows(h->n_slots, -1);
+        for (int i = 0; i < h->n_slots; i++) if (h->slots[i].active) rows[i] = h->y2_rows++;
+        h->y2_pitch = (size_t)NVX_Y2_PREFIX + (size_t)cfg->max_frames * NVX_Y2_PER_FRAME;
+        CR_TRY(hipMalloc(&h->d_y2row, (size_t)h->n_slots * sizeof(int)));
+        CR_TRY(hipMemcpy(h->d_y2row, rows.data(), (size_t)h->n_slots * sizeof(int), hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y2[i], (size_t)h->y2_rows * h->y2_pitch * sizeof(double2)));
+    }
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_dd[i], (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
     CR_TRY(hipMalloc(&h->d_di, (size_t)NVX_DEMOD_INTS * h->n_slots * sizeof(int)));
     CR_TRY(hipMalloc(&h->d_fsm_tab, NVX_FSM_TABLE_ALLOC * sizeof(uint32_t)));
@@ -192,7 +202,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipHostMalloc((void **)&r.h_part, (size_t)h->n_in * sizeof(nvx_part), hipHostMallocDefault));
         CR_TRY(hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
-        for (int i = 0; i < 6; i++) CR_TRY(hipEventCreate(&r.ev[i]));
+        for (int i = 0; i < 8; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
     if (cfg->wideband) {
         CR_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
@@ -250,6 +260,9 @@ extern "C" int nvx_reset(nvx_handle *h)
         h->wide_launches = 0;
     }
     for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_cstate[i], 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
+    // FIR3's history: silence in front of every chain's first launch (the prefix of every y2 row, both buffers)
+    for (int i = 0; i < 2 && h->d_y2[i]; i++)
+        HIP_TRY(hipMemset2DAsync(h->d_y2[i], h->y2_pitch * sizeof(double2), 0, (size_t)NVX_Y2_PREFIX * sizeof(double2), (size_t)h->y2_rows, h->stream));
     for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_dd[i], 0, (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double), h->stream));
     // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting)
     std::vector<int> ints((size_t)NVX_DEMOD_INTS * h->n_slots, 0);
@@ -378,6 +391,8 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
     ca.stage0_order = h->cfg.stage0_order;
     ca.third0 = (unsigned)(h->g0s[0] / (NVX_FRAME_Y3 / 3));        // the state blocks' tag (nvx_kernels.h): position in thirds of a frame
+    // FIR2 output buffers (fused wideband kernel): with a list [parity of the stream]; without one the buffer to write as [0]
+    double2 *const y2_bufs[2] = { h->d_y2[d_list ? 0 : p0], h->d_y2[d_list ? 1 : p0 ^ 1] };
     ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : (demod_overlap > 1 ? demod_overlap : (demod_overlap == 1 ? -1 : 0));
     nvx_demod_args da{};
     da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
@@ -400,6 +415,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
         wa.hist[0] = h->d_whist[p0]; wa.hist[1] = h->d_whist[p0 ^ 1];       // a stream reads [its parity], writes the other
         wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
         wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done; wa.third0 = ca.third0;
+        wa.y2[0] = y2_bufs[0]; wa.y2[1] = y2_bufs[1]; wa.y2_pitch = h->y2_pitch; wa.y2_row = h->d_y2row;
         HIP_TRY(nvx_launch_wideband_fused(&wa, st));
         h->wide_launches++;
     } else {
@@ -412,6 +428,16 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
     if (sd != st) HIP_TRY(hipStreamWaitEvent(sd, h->casc_done[yb], 0));
     else if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
+    if (fused) {
+        // FIR3 (the fused wideband kernel's waves end at FIR2): y2 rows -> y3[yb], in front of the demodulator on its stream
+        nvx_fir3_args fa{};
+        fa.y2[0] = y2_bufs[0]; fa.y2[1] = y2_bufs[1]; fa.y2_pitch = h->y2_pitch; fa.y2_row = h->d_y2row;
+        fa.y3 = h->d_y3[yb]; fa.y3_cap = (size_t)h->y3_cap; fa.y3_base = 0; fa.n_frames = n_frames; fa.n_slots = h->n_slots;
+        fa.part = d_list; fa.n_part = r.n_part; fa.per_part = per_part;
+        if (r.timed) HIP_TRY(hipEventRecord(r.ev[6], sd));
+        HIP_TRY(nvx_launch_fir3(&fa, sd));
+        if (r.timed) HIP_TRY(hipEventRecord(r.ev[7], sd));
+    }
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[2], sd));
     HIP_TRY(nvx_launch_demod_front(&da, sd));
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[3], sd));
@@ -510,7 +536,9 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
                 HIP_TRY(hipEventElapsedTime(&h->ms[1], r.ev[2], r.ev[3]));
                 HIP_TRY(hipEventElapsedTime(&fsm_ms, r.ev[4], r.ev[5]));
                 h->ms[1] += fsm_ms;                       // "demodulator" = front + FSM
-                h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_count++;
+                h->ms[2] = 0.f;
+                if (h->d_y2[0]) HIP_TRY(hipEventElapsedTime(&h->ms[2], r.ev[6], r.ev[7]));
+                h->ms_sum[0] += h->ms[0]; h->ms_sum[1] += h->ms[1]; h->ms_sum[2] += h->ms[2]; h->ms_count++;
             }
             std::atomic<int> bad_slot{ -1 };
             // the chains of this launch: every slot, or (a launch with a participant list) the 2 * per_part slots of each
@@ -627,14 +655,14 @@ extern "C" size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out,
 }
 
 extern "C" void nvx_enable_timing(nvx_handle *h, int enabled) { if (h) h->timing = enabled != 0; }
-extern "C" float nvx_last_kernel_ms(nvx_handle *h, int which) { return (h && which >= 0 && which < 2) ? h->ms[which] : -1.f; }
+extern "C" float nvx_last_kernel_ms(nvx_handle *h, int which) { return (h && which >= 0 && which < 3) ? h->ms[which] : -1.f; }
 extern "C" int nvx_kernel_time_stats(nvx_handle *h, int which, double *sum_ms, uint64_t *launches, int reset)
 {
-    if (!h || which < 0 || which > 1) return NVX_ERR_ARG;
+    if (!h || which < 0 || which > 2) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     if (sum_ms) *sum_ms = h->ms_sum[which];
     if (launches) *launches = h->ms_count;
-    if (reset) { h->ms_sum[0] = h->ms_sum[1] = 0.0; h->ms_count = 0; }
+    if (reset) { h->ms_sum[0] = h->ms_sum[1] = h->ms_sum[2] = 0.0; h->ms_count = 0; }
     return NVX_OK;
 }
 

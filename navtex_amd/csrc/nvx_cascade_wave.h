@@ -60,11 +60,14 @@ template <int NCH> struct GeoSizes {
 static_assert(Geo<1>::Y2_RUN % Geo<1>::Y2_PER_RUN == 0 && Geo<2>::Y2_RUN % Geo<2>::Y2_PER_RUN == 0, "NVX_Y2_RUN: a whole number of FIR2 runs (160)");
 static_assert(Geo<1>::U_RUN % 32 == 0 && Geo<2>::U_RUN % 16 == 0 && 46 + Geo<1>::U_LEFT_MAX <= 128 && 46 + Geo<2>::U_LEFT_MAX <= 128, "slide covers two rows of 64");
 
-template <int NCH>
-struct CascadeLds {
+// F3IN: FIR3 runs inside the wave (the single-wave cascade kernels) and its input buffer Y2 lives here; without it (the
+// fused wideband kernel, r4) the wave ends at FIR2, whose outputs go straight to HBM (nvx_kernels.h, nvx_fir3.hip)
+template <int NCH, bool F3IN> struct CascadeLdsY2 { double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES]; };
+template <int NCH> struct CascadeLdsY2<NCH, false> {};
+template <int NCH, bool F3IN = true>
+struct CascadeLds : CascadeLdsY2<NCH, F3IN> {
     double2 X[X_ENTRIES];
     double2 U[NCH][GeoSizes<NCH>::U_ENTRIES];
-    double2 Y2[NCH][GeoSizes<NCH>::Y2_ENTRIES];
 #ifndef NVX_MIX_GLOBAL
     double2 mix[2][2 * NVX_MIX_N];      // [sign of the cross term][two periods of (cos, -+sin)]
 #endif
@@ -227,9 +230,9 @@ __device__ __forceinline__ bool seal_ok(unsigned long long got, unsigned long lo
 
 // One wave's share of the cascade.  lane = 2 * (pair / output index) + component, in stage 0, FIR1, the mixer, FIR2
 // and FIR3 alike.
-template <int NCH>
+template <int NCH, bool F3IN = true>
 struct CascadeWave {
-    CascadeLds<NCH> *lds;
+    CascadeLds<NCH, F3IN> *lds;
     int lane, half, comp;
     const lds_vdouble *xrv;              // FIR1 read base: sample 8*half + t is component comp of X[(t & 7) * XS + XH + half + floor(t / 8)]
 #ifdef NVX_MIX_GLOBAL
@@ -244,11 +247,14 @@ struct CascadeWave {
     int chain_of_slot0;                  // NCH == 1: the single active chain; NCH == 2: chain slot c is chain c
     int n_u, n_y2, n3_done, mixbase;
     nvx_d2 mix_next;                     // mixer table entry of the NEXT pass's first output (= this pass's second one)
-    bool emit;                           // FIR3 outputs are written (false during a pre-roll)
+    bool emit;                           // outputs are written (false during a pre-roll)
     double2 *y3; size_t y3_row0, y3_cap;
+    // !F3IN: where this lane's FIR2 outputs go -- the unit's first output of the lane's chain in the y2 buffer (nullptr: the
+    // chain is not decoded) -- and how many outputs per chain the unit has written so far
+    double2 *y2_lane; int n2_done;
 
     // once per kernel: lane constants, the taps, the mixer table of this wave's LDS block
-    __device__ __forceinline__ void init(CascadeLds<NCH> *l, int lane_)
+    __device__ __forceinline__ void init(CascadeLds<NCH, F3IN> *l, int lane_)
     {
         lds = l; lane = lane_; half = lane >> 1; comp = lane & 1;
         xrv = (const lds_vdouble *)((const double *)&lds->X[XH + half] + comp);
@@ -287,8 +293,17 @@ struct CascadeWave {
         mixrow = (const lds_vd2 *)&lds->mix[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
 #endif
         y3 = y3_; y3_row0 = row0; y3_cap = cap;
-        mixbase = mixbase0; n_u = n_u0; n_y2 = n_y20; n3_done = 0; emit = emit0;
+        mixbase = mixbase0; n_u = n_u0; n_y2 = n_y20; n3_done = 0; n2_done = 0; emit = emit0;
         mix_next = mixrow[mixbase];      // (behind init()'s table writes in this wave's LDS queue)
+    }
+
+    // !F3IN, once per unit: the y2 buffer of the stream's parity, the rows of its two chains (-1: not decoded), the unit's
+    // first output within a row
+    __device__ __forceinline__ void begin_unit_y2(double2 *y2buf, size_t pitch, int row0, int row1, size_t first)
+    {
+        const int ch = (NCH == 1) ? chain_of_slot0 : (lane >> 5);           // the chain this lane computes FIR2 outputs of
+        const int row = ch ? row1 : row0;
+        y2_lane = row < 0 ? nullptr : y2buf + ((size_t)row * pitch + NVX_Y2_PREFIX + first);
     }
 
     // filter histories from the state block: 36 newest 252 kS/s samples (oldest first), then per chain 46 mixer outputs
@@ -307,10 +322,12 @@ struct CascadeWave {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             const double2 *su = st_in + 36 + ch * (46 + 70);
             if (lane < 46) { const double2 u = state_load(su + lane); f ^= (c ? seal_pair<4>(u) : seal_pair<1>(u)); lds->U[c][lane] = u; }
-            const double2 y = state_load(su + 46 + lane);
-            f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
-            lds->Y2[c][lane] = y;
-            if (lane < 6) { const double2 t = state_load(su + 46 + 64 + lane); f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); lds->Y2[c][64 + lane] = t; }
+            if constexpr (F3IN) {
+                const double2 y = state_load(su + 46 + lane);
+                f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
+                lds->Y2[c][lane] = y;
+                if (lane < 6) { const double2 t = state_load(su + 46 + 64 + lane); f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); lds->Y2[c][64 + lane] = t; }
+            }
         }
         return f;
     }
@@ -322,7 +339,7 @@ struct CascadeWave {
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             for (int i = lane; i < 46 + NVX_PREROLL_U; i += 64) lds->U[c][i] = zero;
-            for (int i = lane; i < 70 + NVX_PREROLL_Y2; i += 64) lds->Y2[c][i] = zero;
+            if constexpr (F3IN) for (int i = lane; i < 70 + NVX_PREROLL_Y2; i += 64) lds->Y2[c][i] = zero;
         }
     }
     // ... and back; returns this lane's share of the fold over what it STORED
@@ -340,10 +357,12 @@ struct CascadeWave {
             const int ch = (NCH == 1) ? chain_of_slot0 : c;
             double2 *su = st + 36 + ch * (46 + 70);
             if (lane < 46) { const double2 u = lds->U[c][lane]; f ^= (c ? seal_pair<4>(u) : seal_pair<1>(u)); state_store(su + lane, u); }
-            const double2 y = lds->Y2[c][lane];
-            f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
-            state_store(su + 46 + lane, y);
-            if (lane < 6) { const double2 t = lds->Y2[c][64 + lane]; f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); state_store(su + 46 + 64 + lane, t); }
+            if constexpr (F3IN) {
+                const double2 y = lds->Y2[c][lane];
+                f ^= (c ? seal_pair<5>(y) : seal_pair<2>(y));
+                state_store(su + 46 + lane, y);
+                if (lane < 6) { const double2 t = lds->Y2[c][64 + lane]; f ^= (c ? seal_pair<6>(t) : seal_pair<3>(t)); state_store(su + 46 + 64 + lane, t); }
+            }
         }
         return f;
     }
@@ -440,7 +459,12 @@ struct CascadeWave {
                     if constexpr (i + NVX_F23_AHEAD < NVX_T2) { NVX_PIN_AFTER(acc); xs2[i + NVX_F23_AHEAD] = ub[2 * (52 - (i + NVX_F23_AHEAD))]; }
                     acc += NVX_TAP(NVX_H2, i) * xs2[i];
                 });
-                if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds->Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
+                if constexpr (F3IN) {
+                    if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds->Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
+                } else {
+                    // the 9 kS/s output leaves the wave here: 32 (16 per chain) consecutive {I,Q} pairs, 512 contiguous bytes
+                    if (emit && y2_lane) ((double *)(y2_lane + n2_done + f2o))[comp] = acc;
+                }
             }
             NVX_WAVE_LDS_FENCE();
             // drop the consumed inputs: keep 46 history + pending (<= 46 + U_LEFT_MAX entries)
@@ -452,10 +476,11 @@ struct CascadeWave {
             }
             NVX_WAVE_LDS_FENCE();
             n_u -= U_RUN;
+            if constexpr (!F3IN) { if (emit) n2_done += Y2_PER_RUN; continue; }
             n_y2 += Y2_PER_RUN;
 
             // ---- FIR3 when a batch of FIR2 outputs is pending
-            if (n_y2 >= Y2_RUN) {
+            if constexpr (F3IN) if (n_y2 >= Y2_RUN) {
                 // lanes 0 .. 2*Y3_PER_RUN-1 hold chain 0 (output, component); with two chains the
                 // next 2*Y3_PER_RUN lanes hold chain 1
                 const int f3c = (NCH == 2) ? ((lane >> 4) & 1) : 0;

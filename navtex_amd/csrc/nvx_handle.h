@@ -60,7 +60,7 @@ struct Result {                        // one in-flight launch's bit output
     unsigned long long g0_all = 0;     // no list: the 900 S/s sample count every stream had when the launch went out
     hipEvent_t copied = nullptr;       // push mode: the launch's host-to-device copies have left the staging sets
     hipEvent_t done = nullptr;
-    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM
+    hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // begin/end of cascade, demod front, demod FSM, nvx_fir3
     bool timed = false;
     bool pending = false;
 };
@@ -130,6 +130,11 @@ struct nvx_handle {
     uint8_t *d_masks = nullptr, *d_active = nullptr;
     uint8_t *d_cstate[2] = { nullptr, nullptr };   // cascade state blocks: launch k reads [k & 1], writes [(k + 1) & 1]
     double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
+    // 252 kS/s and wideband handles (the cascade kernels end at FIR2, nvx_kernels.h): FIR2 output rows, one per active
+    // chain, two buffers by stream parity; the row table; the HIP-event time of nvx_fir3
+    double2 *d_y2[2] = { nullptr, nullptr };
+    int *d_y2row = nullptr;
+    size_t y2_pitch = 0; int y2_rows = 0;
     double *d_dd[2] = { nullptr, nullptr };   // demodulator state blocks: a chain reads [its stream's parity], writes the other
     double *d_dphi = nullptr; int *d_di = nullptr;
     uint32_t *d_fsm_tab = nullptr;     // bit-period transition table of the demodulator FSM (nvx_fsm.h)
@@ -154,8 +159,8 @@ struct nvx_handle {
     int last_n3 = 0;
     // timing
     bool timing = false;
-    float ms[2] = { 0.f, 0.f };          // last collected launch
-    double ms_sum[2] = { 0.0, 0.0 };     // over all collected launches since the last stats reset
+    float ms[3] = { 0.f, 0.f, 0.f };     // last collected launch: cascade, demodulator (front + FSM), nvx_fir3
+    double ms_sum[3] = { 0.0, 0.0, 0.0 };   // over all collected launches since the last stats reset
     uint64_t ms_count = 0;
     // host
     std::vector<uint8_t> masks;

@@ -16,6 +16,18 @@
  * launch shorten the ragged end of the persistent grid from a frame to a third (nvx_cascade.hip, DESIGN.md tuning log). */
 #define NVX_THIRD_PASSES (NVX_PASSES_PER_FRAME / 3)
 #define NVX_THIRD_Y3 (NVX_Y3_PER_FRAME / 3)
+/* r4: the waves of the fused wideband kernel (nvx_wideband_fused) end at FIR2: their 9 kS/s outputs go to HBM and FIR3
+ * (71 taps, /10, receiver/fir3cpp.C:22-60) is a kernel of its own (nvx_fir3.hip) in front of the demodulator, beside the
+ * next launch.  Inside the wave FIR3 ran on half of the lanes; out of it the fused kernel is 4.8 % faster and so is the
+ * step.  The single-wave cascade kernels keep FIR3 inside (252 kS/s input: 2.4 % in the kernel, nothing in the step;
+ * raw-rate input: HBM-bound, the extra traffic would cost more) -- nvx_fir3.hip, DESIGN.md tuning log.
+ * y2 rows: one per ACTIVE chain (y2_row[slot], -1 = none), NVX_Y2_PREFIX entries in front of the launch's own outputs;
+ * entries PREFIX-70 .. PREFIX-1 hold the last 70 outputs of the chain's previous launch (FIR3's history).  Two buffers:
+ * a stream of parity p writes the outputs of its launch into [p]; nvx_fir3 reads [p] and leaves the tail in [p ^ 1]'s
+ * prefix for the stream's next launch -- while the next cascade launch already fills [p ^ 1]'s output region.        */
+#define NVX_Y2_PER_FRAME 2880
+#define NVX_THIRD_Y2 (NVX_Y2_PER_FRAME / 3)
+#define NVX_Y2_PREFIX 80
 /* Independent units (launches with fewer streams than resident waves): a unit that is not the first of its
  * stream in the launch rebuilds the filter histories from the input instead of waiting for its predecessor.
  * Every value a real output uses must come from real samples in the reference's operation order:
@@ -99,6 +111,18 @@ typedef struct {
                                /* state block's tag; with a list every entry carries its own g0                                */
 } nvx_cascade_args;
 
+/* FIR3 as a kernel of its own (wideband handles, fused form): y2 rows -> y3, and the rows' tails into the other
+ * buffer's prefix */
+typedef struct {
+    double2 *y2[2];            /* FIR2 output buffers [rows][y2_pitch] (above); a stream of parity p wrote [p]; without a   */
+    size_t y2_pitch;           /* list the host passes the buffer the launch wrote as [0], the other as [1]                  */
+    const int *y2_row;         /* [all decoded streams * 2]: row of the chain, or -1                                         */
+    double2 *y3; size_t y3_cap, y3_base;                    /* [all streams * 2][y3_cap]                        */
+    int n_frames;
+    int n_slots;                                            /* all streams * 2                                  */
+    const nvx_part *part; int n_part, per_part;             /* participants, as nvx_demod_args (NULL = all)      */
+} nvx_fir3_args;
+
 /* How close the bit-timing arg-max (receiver/decoder.C:202-215, strict '>') comes to a tie.  The class sums it compares
  * are built from delta-phi values that may differ from glibc's atan2 in the last bit; such a difference
  * moves a sum by ~1e-16 relative, so it can only change the decision where best and runner-up are closer than that.
@@ -165,6 +189,7 @@ typedef struct {
     int independent;           /* set by the launcher: units pre-roll instead of waiting for their predecessor */
     int thirds;                /* set by the launcher (independent units only): a unit is a third of a frame   */
     unsigned third0;           /* as nvx_cascade_args                                                          */
+    double2 *y2[2]; size_t y2_pitch; const int *y2_row;     /* as nvx_fir3_args (rows by decoded stream * 2 + chain)     */
 } nvx_wideband_args;
 
 #ifdef __cplusplus
@@ -173,6 +198,7 @@ extern "C" {
 hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipStream_t s);
 hipError_t nvx_launch_channelise(const nvx_channelise_args *a, hipStream_t s);
 hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s);
+hipError_t nvx_launch_fir3(const nvx_fir3_args *a, hipStream_t s);
 hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_t s);
 hipError_t nvx_launch_demod_fsm(const nvx_demod_args *a, hipStream_t s);
 hipError_t nvx_launch_synth(const nvx_synth_args *a, int n_streams, hipStream_t s);

@@ -38,7 +38,7 @@
 #define WB_PASS_WORDS 2048
 
 struct WidebandLds {
-    CascadeLds<2> sub[NVX_WB_SUBBANDS_K];
+    CascadeLds<2, false> sub[NVX_WB_SUBBANDS_K];           // the waves end at FIR2 (nvx_kernels.h: FIR3 is nvx_fir3.hip)
     __attribute__((aligned(16))) unsigned raw[40 + WB_PASS_WORDS];
     int unit, ok, bad;
 };
@@ -49,7 +49,7 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
 {
     __shared__ WidebandLds L;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    CascadeWave<2> cw;
+    CascadeWave<2, false> cw;
     cw.init(&L.sub[wave], lane);
     // a unit = a frame, or (a.thirds: independent units only) a third of one -- 105 passes, every pending buffer empty there
     // too (nvx_kernels.h), three times the units for launches that would leave most of the chip idle
@@ -164,6 +164,10 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
         cw.begin_unit(mask, a.y3, (size_t)(s * 2) * a.y3_cap + a.y3_base + (size_t)part * unit_y3, a.y3_cap,
                       a.thirds ? ((part % 3) * (NVX_THIRD_PASSES * 64)) % NVX_MIX_N : 0,
                       preroll ? NVX_PREROLL_U : 0, preroll ? NVX_PREROLL_Y2 : 0, !preroll);
+        {
+            const unsigned long long rows = nvx_load_const_u64(a.y2_row + 2 * s);             // the rows of this sub-band's two chains
+            cw.begin_unit_y2(parity ? a.y2[1] : a.y2[0], a.y2_pitch, (int)(unsigned)rows, (int)(unsigned)(rows >> 32), a.y3_base * 10 + (size_t)part * (NVX_Y2_PER_FRAME / per_frame));
+        }
         NVX_WAVE_LDS_FENCE();
         if (preroll) {
             cw.state_zero();

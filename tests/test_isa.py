@@ -36,6 +36,13 @@ def test_cascade_has_no_fused_multiply_add(isa):
     for name, body in casc.items():
         assert not re.search(r"v_fma_f64|v_fmac_f64|v_fma_f32|v_fmac_f32|v_pk_fma", body), f"{name}: FMA breaks the reference's rounding"
         assert body.count("v_mul_f64") >= 37 * 2 - 2 + 47 + 71        # FIR1 (two outputs per lane; equal taps on one sample share a product) + FIR2 + FIR3, fully unrolled
+    # r4: the fused wideband kernel's waves end at FIR2; its FIR3 is nvx_fir3 -- same contract
+    fused = next(v for k, v in kernels.items() if "nvx_wideband_fused" in k)
+    assert not re.search(r"v_fma_f64|v_fmac_f64", fused) and 37 * 2 - 2 + 47 <= fused.count("v_mul_f64") < 37 * 2 + 47 + 71
+    fir3 = next(v for k, v in kernels.items() if "nvx_fir3" in k)
+    assert not re.search(r"v_fma_f64|v_fmac_f64|v_fma_f32|v_fmac_f32|v_pk_fma", fir3), "nvx_fir3: FMA breaks the reference's rounding"
+    assert fir3.count("v_mul_f64") % 71 == 0 and fir3.count("v_mul_f64") > 0 and fir3.count("v_add_f64") >= 70 and "scratch_" not in fir3
+    assert "ds_read2_b64" not in fir3 and "ds_read2st64_b64" not in fir3
 
 
 def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
@@ -106,4 +113,4 @@ def test_third_order_stage0_code_shape_and_occupancy(isa):
 def test_no_kernel_spills(isa):
     _, meta = isa
     sizes = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", meta)]
-    assert len(sizes) >= 18 + 4 and all(s == 0 for s in sizes), sizes      # 16 + 2 cascade kernels + demod x2, channeliser, generator
+    assert len(sizes) >= 18 + 5 and all(s == 0 for s in sizes), sizes      # 16 + 2 cascade kernels + nvx_fir3 + demod x2, channeliser, generator
