@@ -141,7 +141,8 @@ NVX_API void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds);
  * collect - arrival is booked.  frames: latencies booked so far; p50 / p99 over the last 8192 of them, max and last in
  * ms (-1: none yet); reset != 0 clears afterwards.  The bound a receiver can rely on for a character: 0.32 s (its frame
  * still filling) + what this call reports (launch + collect, a few ms; 50 ms at worst when no callback wakes the
- * consumer) -- INTEGRATION.md section 1.                                                                             */
+ * consumer) -- INTEGRATION.md section 1.  nvx_reset of the handle ends the bookkeeping of an attached ring (the
+ * frames no longer line up); the figures booked so far stay readable.                                                */
 NVX_API int  nvx_capture_latency(nvx_capture *c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset);
 /* debug recording (the reference's debug_mode, capt_sched.c:87-101 PrepWav/EndWav and :516):
  * every span the consumer hands to the pipeline is also appended to a 2-channel 16-bit WAV

@@ -251,6 +251,10 @@ extern "C" int nvx_reset(nvx_handle *h)
     std::fill(h->parity.begin(), h->parity.end(), (uint8_t)0);
     std::fill(h->g0s.begin(), h->g0s.end(), 0ull);
     h->diverged = false;
+    // a reset drops whatever was staged: the frames of an attached capture ring and the handle's no longer line up, so its
+    // latency bookkeeping ends here (nvx_capture_latency keeps what it has; a new nvx_capture_start books again)
+    for (ArrivalClock *ac : h->arrival)
+        if (ac) { std::lock_guard<std::mutex> al(ac->mu); ac->base = UINT64_MAX; }
     h->demod_pending[0] = h->demod_pending[1] = false;
     h->fsm_pending = false;
     if (h->stream3) {

@@ -96,6 +96,44 @@ def test_any_changed_bit_of_the_inherited_state_fails_the_launch(nv, raw, masks,
         p.close(); buf.free()
 
 
+def test_a_changed_bit_in_a_wideband_handles_state_fails_the_launch(nv):
+    """The fused wideband kernel seals nine blocks per work unit: the filter state of its eight sub-bands (one wave each: the
+    252 kS/s window and both chains' mixer outputs -- its waves end at FIR2, so no FIR2-output history) and, with
+    sub-band 7's block, the 40-sample channeliser halo.  One changed bit in any carried word of any sub-band's block fails
+    the next launch; the words a sub-band's wave does not carry do not."""
+    W, F = 2, 2
+    n = 2 * F * nv.FRAME_RAW
+    rng = np.random.default_rng(9)
+    raw = rng.integers(-9000, 9000, size=(W, n, 2), dtype=np.int16)
+    buf = nv.DeviceBuffer(W * n * 4)
+    buf.upload(raw)
+    covered = list(range(0, 2 * 36)) + [w for ch in range(2) for w in range(2 * (36 + 116 * ch), 2 * (36 + 116 * ch + 46))] + [W_SEAL]
+    free = [2 * (36 + 46) + 5, 2 * (36 + 116 + 46) + 8, W_TAG, W_PAD]
+    failures = 0
+    with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=False) as p:
+        trial = 0
+        for s in (0, 3, 7, 8 + 7, 8 + 2):                       # decoded streams 8 w + k: several sub-bands of both wideband streams
+            for w in [covered[0], covered[-1], covered[-2], 70, 2 * 36 + 3] + [int(x) for x in rng.choice(covered, 6)] + free:
+                p.reset()
+                p.process_resident(buf, n, 0, F); p.fetch()
+                blk = p.debug_state(s)
+                assert int(blk[W_TAG]) == (s << 32) | (3 * F)
+                blk[w] ^= np.uint64(1) << np.uint64((11 * trial + 5) % 64); trial += 1
+                p.debug_set_state(s, blk)
+                p.process_resident(buf, n, F, F)
+                if w in covered:
+                    with pytest.raises(nv.NvxError, match="integrity"):
+                        p.fetch()
+                    failures += 1
+                else:
+                    p.fetch()
+                assert p.integrity_stats()[1] == failures, (s, w)
+        p.reset()
+        p.process_resident(buf, n, 0, F); p.process_resident(buf, n, F, F); p.fetch()
+        assert p.integrity_stats()[0] == 0 and len(p.bits(5, 1)) > 40
+    buf.free()
+
+
 def test_the_seal_is_sensitive_to_position(nv):
     """Two entries swapped (same lane's slots: U and Y2; neighbouring lanes: Y2[k] and Y2[k+1]; across the halves of the
     wave: lanes 5 and 37), a block of the right stream but an EARLIER position (the block two launches old), and the block

@@ -41,6 +41,9 @@ with nv.Pipeline(n_streams=S, raw_rate=True, chain_mask=nv.CHAIN_518, max_frames
         if run % 10 == 9:
             print(f"run {run + 1}: identical; {time.time() - t0:.0f} s", flush=True)
     polls, units, launches = p.wait_stats()
+    stale, failures, _ = p.integrity_stats()
 print(f"{N} full-size runs in three launch partitions: all 4096 streams' bits identical run to run, 64 checked against the oracle per partition; "
-      f"{units} units pre-rolled or waited over {launches} launches")
+      f"{units} units pre-rolled or waited over {launches} launches; seals (r4): about {N * S * (F + 1)} hand-overs checked, "
+      f"{stale} stale / torn blocks repaired, {failures} launches failed the check of their inherited state")
+assert stale == 0 and failures == 0
 buf.free()

@@ -42,5 +42,7 @@ with nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_la
         p._bits.clear()
         if i % 10 == 0:
             print(f"launch {i}: ok so far ({time.time() - t0:.0f} s)", flush=True)
-polls, units, launches = 0, 0, 0
-print(f"done: {N} launches x {W * F} units (8 sub-bands each), {bad} failures, {time.time() - t0:.0f} s")
+    stale, failures, launches = p.integrity_stats()
+print(f"done: {N} runs x {W * F} units (8 sub-bands each), {bad} failures, {time.time() - t0:.0f} s; seals (r4): nine blocks per hand-over, "
+      f"{stale} workgroup hand-overs repaired, {failures} launches failed the check of their inherited state, {launches} launches")
+sys.exit(1 if bad or stale or failures else 0)
