@@ -226,19 +226,16 @@ def self_launch(args, script=None, argv=None) -> None:
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         signal.signal(sig, pass_on)
     out, _ = child.communicate()
-
-    class proc:                                   # what the relay below reads
-        stdout, returncode = out, child.returncode
-    lines = proc.stdout.splitlines()
+    lines = out.splitlines()
     js = [l for l in lines if l.startswith("{")]
     for l in lines:
         if not js or l is not js[-1]:
             print(l, file=sys.stderr)
     if js:
         print(js[-1], flush=True)
-    elif proc.returncode == 0:
+    elif child.returncode == 0:
         raise SystemExit("bench.py: the ranks printed no JSON line")
-    sys.exit(proc.returncode)
+    sys.exit(child.returncode)
 
 
 def traffic_record(S: int, F: int, order: int):
