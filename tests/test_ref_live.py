@@ -126,3 +126,18 @@ def test_capt_sched_dsp_symbols_resolve_from_the_library(nv):
     undefined = subprocess.run(["nm", "-D", "--undefined-only", str(lib)], capture_output=True, text=True, check=True).stdout
     for sym in ("sample_in_2", "init_fir_filter2", "fir_filter3", "decoder", "byte_state_machine", "_Z10fir_in_2"):
         assert sym not in undefined
+
+
+def test_replay_is_what_the_reference_does_with_the_same_frames_again(nv, oracle):
+    """bench.py's parity gate AFTER its timed region rests on nvxo_replay: the same frames pushed `loops` times into one
+    pipe, state carried from repeat to repeat.  The reference carries that state in its statics (receiver/fir1cpp.C:51-60,
+    receiver/fir2cpp.C:74-83, receiver/fir3cpp.h:90-95, receiver/decoder.h:31-60): fed the frames repeated as ONE stream,
+    the compiled reference itself must produce the replay's bits, on both chains."""
+    import signals
+    n = 3 * nv.FRAME_IN
+    car = [dict(freq_hz=f, bits=nv.sitor_encode(signals.stream_text(71), 8), bit_offset=517, phase0=777 * k, amplitude=5500) for k, f in enumerate((14000, -14000))]
+    iq = nv.synth_host(nv.make_stream(car, seed=71, noise_amp=1800), nv.RATE_IN, n)
+    loops = 4
+    _s, got = oracle.replay(iq[None], 1, n, False, 3, 1, loops)
+    ref = ob.run_ref("bits", np.concatenate([iq] * loops).tobytes())
+    assert got[0] == [ref["bits518"].decode(), ref["bits490"].decode()] and len(got[0][0]) > 300
