@@ -207,10 +207,15 @@ NVX_API int  nvx_reset(nvx_handle *h);
  * and covers all of them; when one stream's staging is full (max_frames + 1
  * frames) before that, the launch goes out with the streams that HAVE a frame,
  * each carrying its own filter / demodulator state -- a stalled or slower
- * radio never blocks the others, and rejoins later bit-exactly.  Returns
- * NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel form).
+ * radio never blocks the others, and rejoins later bit-exactly.  A stream
+ * that has delivered nothing for 2 s (no capture ring needed: the handle keeps
+ * the time of every stream's last push) is not waited for either, so the
+ * others keep launching frame by frame; its next push counts again at once.
+ * Returns NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel
+ * form).
  * Threads: any number of threads may push into one handle, ONE per stream at
- * a time (a second pusher of the same stream waits).  Pushes of 128 KB and
+ * a time (a second pusher of the same stream waits until the first one's call
+ * has returned: a push call is atomic against other pushes of its stream).  Pushes of 128 KB and
  * more copy into the pinned staging without the handle's lock, so the capture
  * or replay threads of several radios fill their streams side by side; a
  * launch first waits for the copies in flight to be committed.              */
