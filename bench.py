@@ -852,7 +852,8 @@ def run_group(args):
     after_m, bad_after, after_s = [], [], 0.0
     for m, (dev, first, count) in enumerate(group.members):
         ids = fullsize.spread(S, min(S, max(32, args.after_timed)))
-        c, bad, secs = fullsize.verify_replay(ob, bufs[m], pitch, n_per_stream, oraw, lambda s, f=first: group.bits(f + s, 0), ids, threads, loops)
+        c, bad, secs = fullsize.verify_replay(ob, bufs[m], pitch, n_per_stream, oraw, lambda s, f=first: group.bits(f + s, 0), ids, threads, loops,
+                                              gpu_count=lambda s, f=first: group.bit_count(f + s, 0))
         after_m.append(c); bad_after += [first + b for b in bad]; after_s += secs
     if bad_all or bad_after:
         print(f"PARITY FAILURE (group): first launch {len(bad_all)} streams differ (first {bad_all[:8]}), after the timed region {len(bad_after)} (first {bad_after[:8]})", file=sys.stderr)
@@ -984,8 +985,11 @@ def main():
     nv.synth_device(streams, RATE, n_per_stream, buf, pitch)
     t_gen = time.time() - t0
 
+    # (the handle keeps a bounded poll history per chain -- a receiver runs for weeks --; the gate behind the timed region wants
+    # everything decoded over warm-up + timed launches)
     pipe = nv.Pipeline(n_streams=S, raw_rate=raw, chain_mask=nv.CHAIN_518, max_frames=F,
-                       char_layer=not args.no_charlayer, device=device, stage0_order=order)
+                       char_layer=not args.no_charlayer, device=device, stage0_order=order,
+                       bit_history=max(65536, (args.warmup + args.steps + 1) * F * 32 + 4096))
     ncpu = place["threads"]
 
     # ---- parity gate: EVERY rank checks its own shard against the oracle, from reset state -----------------------
@@ -1039,7 +1043,8 @@ def main():
     # ~(warmup + steps) x S x F unit hand-overs.  The oracle is fed the same frames as many times; every bit must agree.
     loops = args.warmup + args.steps
     ids_after = fullsize.spread(S, min(S, max(32, args.after_timed)))
-    checked_after, bad_after, after_s = fullsize.verify_replay(ob, buf, pitch, n_per_stream, oraw, lambda s: pipe.bits(s, 0), ids_after, ncpu, loops)
+    checked_after, bad_after, after_s = fullsize.verify_replay(ob, buf, pitch, n_per_stream, oraw, lambda s: pipe.bits(s, 0), ids_after, ncpu, loops,
+                                                                   gpu_count=lambda s: pipe.bit_count(s, 0))
     if bad_after:
         print(f"PARITY FAILURE AFTER THE TIMED REGION (rank {rank}): {len(bad_after)} of {checked_after} streams differ from the CPU oracle "
               f"after {loops} launches, first {bad_after[:8]}", file=sys.stderr)
