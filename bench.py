@@ -694,7 +694,8 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     raw = nv.DeviceBuffer(W * n_raw * 4, device=device)
     nv.synth_device(wideband_streams(nv, signals, rank, W), nv.RATE_RAW, n_raw, raw, n_raw)
     t_gen = time.time() - t0
-    pipe = nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device)
+    pipe = nv.Pipeline(n_streams=W, wideband=True, chain_mask=3, max_frames=F, char_layer=not args.no_charlayer, device=device,
+                       bit_history=max(65536, (args.warmup + args.steps + 1) * F * 32 + 4096))
 
     def step():
         pipe.process_resident(raw, n_raw, 0, F)
@@ -743,6 +744,18 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     own_elapsed = time.perf_counter() - t0
     ranks.sync()
     elapsed = ranks.reduce(time.perf_counter() - t0, "max")
+    # ---- parity AFTER the timed region, as in the headline mode: the first wideband streams' 16 carriers each, everything
+    # decoded over warm-up + timed launches (channeliser halo, filter and demodulator state carried) against the oracle's replay
+    nw_after = min(W, 8)
+    part_after = raw.download(nw_after * n_raw * 4, dtype=np.int16).reshape(nw_after, n_raw, 2)
+    _secs, want_after = ob.replay_wide(part_after, nw_after, n_sub, ncpu, args.warmup + args.steps)
+    ok_after = [pipe.bits(s, c) for s in range(8 * nw_after) for c in (0, 1)] == want_after and all(len(b) > 0 for b in want_after)
+    if not ok_after:
+        print(f"PARITY FAILURE AFTER THE TIMED REGION (wideband, rank {rank}): GPU bits differ from the CPU oracle's replay", file=sys.stderr)
+    parity_after = ranks.reduce(1.0 if ok_after else 0.0, "min") > 0.5
+    parity = parity and parity_after
+    stale, seal_failures, _ = pipe.integrity_stats()
+    stale_all, seal_failures_all = int(ranks.reduce(float(stale), "sum")), int(ranks.reduce(float(seal_failures), "sum"))
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
     ch_ms, n_c = nv.channelise_time_stats()
@@ -770,14 +783,17 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                      "traffic": None, "flop_per_sample": round(fps, 2), "samples_per_launch": sub_samples,
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
                      "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F * (1 if n_c == 0 else 8)), 4),
-                                 "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1)},
+                                 "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1),
+                                 "stale_detected": stale_all, "launches_failed_integrity": seal_failures_all},
                      "algorithmic_bytes_per_launch": W * n_raw * 4,
                      "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes; "
                              "only the cascade's fp64 operations are counted, the channeliser's integer work rides on top"},
         "channeliser": None if fused else {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
                         "read_plus_write_gbs": round((W * n_raw * 4 + sub_samples * 4) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
         "form": "fused (one kernel, sub-bands stay in LDS)" if fused else "two kernels (NVX_WB_FUSED=0)",
-        "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "demod": {"near_ties": near_ties},
+        "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "parity_after_timed": parity_after,
+        "parity_after_timed_streams": int(ranks.reduce(16.0 * nw_after, "sum")), "parity_after_timed_launches": args.warmup + args.steps,
+        "demod": {"near_ties": near_ties},
         "host_threads": place["threads"], "placement": place, "gen_seconds": round(t_gen, 1),
         "ranks": ranks.describe(own_elapsed / args.steps * 1e3, 16 * nw, casc_avg, device),
     }
