@@ -200,7 +200,12 @@ def test_injected_stale_hand_overs_are_caught_repaired_and_counted():
     left): every kernel family still equals the oracle bit for bit -- complete 900 S/s output and bits -- and the seal
     counted the repairs, in the cascade kernels with and without a participant list and in the fused wideband kernel
     (state of one sub-band, the channeliser halo alone, everything)."""
-    assert INJECT.exists(), "build it with `python navtex_amd/build.py --inject` (__graft_entry__.build() does)"
+    if not INJECT.exists():                                  # a fresh checkout on the GPU box: build it here, as conftest does for the product library
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("nvx_build", ROOT / "navtex_amd" / "build.py")
+        build = importlib.util.module_from_spec(spec); spec.loader.exec_module(build)
+        build.build_variant("inject", build.INJECT_FLAGS)
+    assert INJECT.exists(), "python navtex_amd/build.py --inject (__graft_entry__.build() does it)"
     rec = _run({"NAVTEX_AMD_LIB": str(INJECT)}, waiting_units=False)       # the default unit form: parity only
     assert all(c["ok"] and c.get("failed", 0) == 0 for c in rec["cases"]), rec
     rec = _run({"NAVTEX_AMD_LIB": str(INJECT)})
