@@ -79,6 +79,13 @@ int add_message(char *bbbb, char *message, int freq);
  * yet complete (up to 0.32 s of signal); a program that ends a capture calls
  * it once, an endless receiver (capt_sched.c:618-621) never needs to.       */
 NVX_API int nvx_shim_flush(void);
+/* Decode latency of this surface, per frame of 0.32 s: from the entry of the sample_in_1 call (or singleton stream
+ * callback) that carried the frame's last sample to its bits being pollable and its messages delivered to
+ * add_message -- booked as nvx_capture_latency books a capture ring's (section B').  The reference decodes inline
+ * (receiver/nav_b_sm.C:87 is called from inside sample_in_1's call chain); a character here is at most 0.32 s (its frame
+ * still filling) + this behind it.  frames: latencies booked since init_fir_filter1; p50 / p99 over the last 8192, max
+ * and last in ms (-1: none yet); reset != 0 clears afterwards.                                                       */
+NVX_API int nvx_shim_latency(uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset);
 /* Bits the singleton has produced so far for chain 0 (518) / 1 (490).        */
 NVX_API size_t nvx_shim_bits(int chain, char *out, size_t cap);
 

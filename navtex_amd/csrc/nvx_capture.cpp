@@ -143,22 +143,27 @@ extern "C" void nvx_capture_callback(short *xi, short *xq, void *params, unsigne
     c->cv.notify_one();
 }
 
-extern "C" int nvx_capture_latency(nvx_capture *c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset)
+void nvx_clock_report(ArrivalClock &c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset)
 {
-    if (!c) return NVX_ERR_ARG;
     std::vector<float> v;
     {
-        std::lock_guard<std::mutex> lk(c->clock.mu);
-        v = c->clock.lat_ms;
-        if (frames) *frames = c->clock.booked;
-        if (max_ms) *max_ms = c->clock.max_ms;
-        if (last_ms) *last_ms = c->clock.last_ms;
-        if (reset) { c->clock.lat_ms.clear(); c->clock.booked = 0; c->clock.max_ms = 0.f; c->clock.last_ms = 0.f; }
+        std::lock_guard<std::mutex> lk(c.mu);
+        v = c.lat_ms;
+        if (frames) *frames = c.booked;
+        if (max_ms) *max_ms = c.booked ? (double)c.max_ms : -1.0;
+        if (last_ms) *last_ms = c.booked ? (double)c.last_ms : -1.0;
+        if (reset) { c.lat_ms.clear(); c.booked = 0; c.max_ms = 0.f; c.last_ms = 0.f; }
     }
     std::sort(v.begin(), v.end());
     auto pct = [&](double q) { return v.empty() ? -1.0 : (double)v[std::min(v.size() - 1, (size_t)(q * (double)v.size()))]; };
     if (p50_ms) *p50_ms = pct(0.50);
     if (p99_ms) *p99_ms = pct(0.99);
+}
+
+extern "C" int nvx_capture_latency(nvx_capture *c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset)
+{
+    if (!c) return NVX_ERR_ARG;
+    nvx_clock_report(c->clock, frames, p50_ms, p99_ms, max_ms, last_ms, reset);
     return NVX_OK;
 }
 

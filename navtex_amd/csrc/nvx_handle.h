@@ -98,6 +98,8 @@ struct ArrivalClock {
     }
 };
 int64_t nvx_now_ns();
+// what nvx_capture_latency / nvx_shim_latency report from a clock (any out pointer may be null)
+void nvx_clock_report(ArrivalClock &c, uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset);
 
 struct nvx_handle {
     nvx_config cfg{};

@@ -28,6 +28,10 @@ static nvx_handle *g_shim = nullptr;
 static std::mutex g_shim_mu;                     // callback re-entrancy (capt_sched.c:111)
 static int16_t g_shim_buf[2 * 4096];
 static size_t g_shim_n = 0;
+// Decode latency of this surface, booked like a capture ring's (nvx_handle.h, ArrivalClock): the moment the call that
+// carried a frame's LAST sample was entered -> its bits pollable and its messages at add_message (nvx_shim_latency).
+static ArrivalClock g_shim_clock;
+static uint64_t g_shim_samples = 0;              // samples taken since init_fir_filter1
 
 static void shim_fatal(const char *what)
 {
@@ -72,16 +76,25 @@ static void shim_require(void)
     c.max_frames = 4; c.char_layer = 1; c.push_mode = 1;
     if (const char *d = getenv("NAVTEX_AMD_DEVICE")) c.device = atoi(d);
     if (nvx_create(&c, &g_shim) != NVX_OK) shim_fatal("cannot create the GPU pipeline");
+    { std::lock_guard<std::mutex> lk(g_shim->mu); g_shim->arrival[0] = &g_shim_clock; g_shim->n_arrival++; }
     if (!(getenv("NAVTEX_AMD_NO_KEEPER") && atoi(getenv("NAVTEX_AMD_NO_KEEPER")))) {
         g_keeper = std::thread(keeper_loop, g_shim);
         atexit(keeper_stop);                       // joined before the HIP runtime (loaded earlier) tears down
     }
 }
 
+// a push may have sent a launch on its way: wake the housekeeping thread, which then looks every 2 ms until the results are in
+// (asleep it would notice up to 50 ms later: the latency of this surface was wherever its wake-ups happened to fall)
+static void shim_wake_keeper(void)
+{
+    if (g_keeper.joinable() && nvx_launches_in_flight(g_shim) > 0) g_keeper_cv.notify_one();
+}
+
 static void shim_drain(void)
 {
     if (g_shim_n && nvx_push_iq(g_shim, 0, g_shim_buf, g_shim_n) != NVX_OK) shim_fatal("push failed");
     g_shim_n = 0;
+    shim_wake_keeper();
 }
 
 extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
@@ -90,6 +103,8 @@ extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
     shim_require();
     g_shim_n = 0;
     if (nvx_reset(g_shim) != NVX_OK) shim_fatal("reset failed");
+    g_shim_samples = 0;                          // (the reset ended the clock's bookkeeping: frame 0 starts here again)
+    { std::lock_guard<std::mutex> ck(g_shim_clock.mu); g_shim_clock.base = 0; g_shim_clock.stamped = 0; }
 }
 
 extern "C" void init_fir2_wrapper(void)          // receiver/nav_sched.C:19-22
@@ -104,7 +119,19 @@ extern "C" void sample_in_1(double sample_I, double sample_Q)   // receiver/fir1
     if (!g_shim) { std::lock_guard<std::mutex> lk(g_shim_mu); shim_require(); }
     g_shim_buf[2 * g_shim_n] = (int16_t)sample_I;
     g_shim_buf[2 * g_shim_n + 1] = (int16_t)sample_Q;
-    if (++g_shim_n == 4096) shim_drain();
+    ++g_shim_n;
+    // the sample that completes a frame goes to the pipeline at once (its launch should not wait for up to 4095 more
+    // samples, 16 ms at the real rate), and the frame's arrival is stamped for the latency bookkeeping
+    const bool frame_complete = ++g_shim_samples % NVX_FRAME_IN == 0;
+    if (frame_complete) g_shim_clock.stamp(g_shim_samples / NVX_FRAME_IN - 1, nvx_now_ns());
+    if (g_shim_n == 4096 || frame_complete) shim_drain();
+}
+
+extern "C" int nvx_shim_latency(uint64_t *frames, double *p50_ms, double *p99_ms, double *max_ms, double *last_ms, int reset)
+{
+    if (!g_shim) { nvx_set_error("shim not initialised"); return NVX_ERR_STATE; }
+    nvx_clock_report(g_shim_clock, frames, p50_ms, p99_ms, max_ms, last_ms, reset);
+    return NVX_OK;
 }
 
 extern "C" int nvx_shim_flush(void)
@@ -127,6 +154,12 @@ extern "C" void nvx_StreamACallback(short *xi, short *xq, void *params, unsigned
     (void)params; (void)reset;                   // ignored by the reference too (capt_sched.c:105-148)
     std::lock_guard<std::mutex> lk(g_shim_mu);
     nvx_handle *h = (nvx_handle *)cbContext;
-    if (!h) { shim_require(); shim_drain(); h = g_shim; }
+    if (!h) {
+        const int64_t t_enter = nvx_now_ns();
+        shim_require(); shim_drain(); h = g_shim;
+        for (uint64_t f = g_shim_samples / NVX_FRAME_IN; f < (g_shim_samples + numSamples) / NVX_FRAME_IN; f++) g_shim_clock.stamp(f, t_enter);
+        g_shim_samples += numSamples;
+    }
     if (nvx_push_planar(h, 0, xi, xq, numSamples) != NVX_OK) shim_fatal("stream callback push failed");
+    if (h == g_shim) shim_wake_keeper();
 }

@@ -191,3 +191,38 @@ def test_nnnn_reaches_add_message_within_the_documented_bound(nv, oracle):
         delay_ms = (t_msg - t_frame) * 1e3
         assert -1.0 <= delay_ms <= 150.0, f"message {delay_ms:.1f} ms after its frame was complete (frame {k_done} of {n_frames})"
         assert lat["frames"] >= n_frames - 2 and lat["max_ms"] < 150.0, lat
+
+
+@pytest.mark.gpu
+def test_the_reference_shaped_surface_at_the_real_rate(nv, oracle, tmp_path):
+    """The surface an unmodified capt_sched.c links against (sample_in_1 per sample, add_message out, no flush ever), driven
+    as capt_sched.c drives it: a consumer that wakes every 50 ms and hands on what has arrived (receiver/capt_sched.c:484-528),
+    at 252 kS/s of wall clock (tests/harness/shim_realtime.c).  The library books the latency of every frame itself
+    (nvx_shim_latency: entry of the sample_in_1 call of the frame's last sample -> bits pollable, messages at add_message):
+    below 100 ms throughout; and the message reaches add_message within 100 ms of the call that completed its frame."""
+    text = "ZCZC RT42\nREAL TIME 5678\nNNNN\n"
+    st, _ = signals.stream_params(nv, 778, nv.RATE_IN, n_phasing=12, text=text)
+    n_frames = 26
+    iq = nv.synth_host(st, nv.RATE_IN, n_frames * nv.FRAME_IN)
+    ref = oracle.Pipe(chain_mask=3, charlayer=True)
+    k_done = None
+    for k in range(n_frames):
+        ref.push(iq[k * nv.FRAME_IN:(k + 1) * nv.FRAME_IN])
+        if ref.messages:
+            k_done = k + 1; break
+    assert k_done is not None and ref.messages[0][:2] == (518, "RT42")
+    data = tmp_path / "iq.bin"; iq.tofile(data)
+    exe = tmp_path / "shim_realtime"
+    lib = ROOT / "navtex_amd"
+    subprocess.run(["gcc", "-O2", str(ROOT / "tests" / "harness" / "shim_realtime.c"), "-o", str(exe), f"-L{lib}", "-lnavtex_amd",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe), str(data)], check=True, capture_output=True, text=True, timeout=120).stdout
+    fed = {int(l.split()[1]): float(l.split()[2]) for l in out.splitlines() if l.startswith("FED ")}
+    msgs = [(float(l.split()[1]), l.split()[2]) for l in out.splitlines() if l.startswith("MSG ")]
+    lat = next(l.split() for l in out.splitlines() if l.startswith("LAT "))
+    frames, p50, p99, worst = int(lat[1]), float(lat[2]), float(lat[3]), float(lat[4])
+    assert len(fed) == n_frames and frames >= n_frames - 1, out[-600:]
+    assert 0 < p50 <= p99 <= worst < 100.0, lat
+    assert msgs and msgs[0][1] == "518|RT42", msgs
+    delay = msgs[0][0] - fed[k_done - 1]
+    assert -1.0 <= delay <= 100.0, f"the message arrived {delay:.1f} ms after the call that completed its frame (frame {k_done})"
