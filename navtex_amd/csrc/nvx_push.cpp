@@ -150,6 +150,13 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
             if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
         }
     }
+    // Launched work that has finished meanwhile is taken in on the way out (never waits): a caller that only ever pushes --
+    // the stream callback on a handle of its own, no ring, no poller -- gets its bits and messages within one callback
+    // interval of their completion instead of with the next launch, a frame later.
+    if (h->collected != h->launched) {
+        int rc = nvx_collect_ready_locked(h);
+        if (rc != NVX_OK) { if (accepted) *accepted = n; return rc; }
+    }
     if (accepted) *accepted = n;
     return NVX_OK;
 }

@@ -13,6 +13,7 @@ extern "C" void nvx_set_error(const char *fmt, ...) { va_list ap; va_start(ap, f
 bool nvx_wb_fused() { return true; }
 int64_t nvx_now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int nvx_collect_locked(nvx_handle *, uint64_t) { return NVX_OK; }
+int nvx_collect_ready_locked(nvx_handle *h) { h->collected = h->launched; return NVX_OK; }      // (called on the way out of every push)
 
 // ---- the "device": d_in is host memory here; a launch appends what it was given to the stream's received sequence
 static std::vector<std::vector<uint32_t>> g_got;      // per stream, under the handle's lock

@@ -226,3 +226,39 @@ def test_the_reference_shaped_surface_at_the_real_rate(nv, oracle, tmp_path):
     assert msgs and msgs[0][1] == "518|RT42", msgs
     delay = msgs[0][0] - fed[k_done - 1]
     assert -1.0 <= delay <= 100.0, f"the message arrived {delay:.1f} ms after the call that completed its frame (frame {k_done})"
+
+
+@pytest.mark.gpu
+def test_stream_callback_on_a_handle_of_its_own_delivers_within_a_callback_interval(nv, oracle):
+    """the SDRplay callback shape on a push-mode handle -- no ring, no poller, the vendor thread is
+    the only caller (receiver/capt_sched.c:105-148 does its work in the callback too).  Every push takes in what has finished
+    meanwhile, so the message is at the sink a few callbacks after its frame was complete -- not a frame later, with the
+    next launch."""
+    from fake_sdr import FakeSdr
+    text = "ZCZC CB09\nCALLBACK ONLY 42\nNNNN\n"
+    st, _ = signals.stream_params(nv, 779, nv.RATE_IN, n_phasing=12, text=text)
+    n_frames = 26
+    iq = nv.synth_host(st, nv.RATE_IN, n_frames * nv.FRAME_IN)
+    ref = oracle.Pipe(chain_mask=1, charlayer=True)
+    k_done = None
+    for k in range(n_frames):
+        ref.push(iq[k * nv.FRAME_IN:(k + 1) * nv.FRAME_IN])
+        if ref.messages:
+            k_done = k + 1; break
+    assert k_done is not None
+
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=True) as p:
+        arrived = []
+        class Vendor:                                           # the vendor library's streaming thread calls this
+            def feed(self, xi, xq):
+                nv.lib.nvx_StreamACallback(xi.ctypes.data, xq.ctypes.data, None, xi.shape[0], 0, p._h)
+                if p.messages and not arrived:
+                    arrived.append(time.monotonic())
+        sdr = FakeSdr(Vendor(), iq, nv.RATE_IN, nv.FRAME_IN, seed=11, packet=(150, 420))
+        sdr.start(); sdr.join()
+        assert arrived and p.messages[0][1:] == ref.messages[0] and sdr.late_ms < 50.0
+        delay_ms = (arrived[0] - sdr.frame_done_at[k_done - 1]) * 1e3
+        assert 0.0 <= delay_ms <= 50.0, f"message {delay_ms:.1f} ms after its frame was complete"
+        p.flush()
+        want = oracle.Pipe(chain_mask=1, charlayer=False); want.push(iq)
+        assert p.bits(0, 0) == want.bits(0)
