@@ -201,6 +201,13 @@ typedef struct nvx_config {
 NVX_API void nvx_config_default(nvx_config *cfg);
 NVX_API int  nvx_create(const nvx_config *cfg, nvx_handle **out);
 NVX_API void nvx_destroy(nvx_handle *h);
+/* Trace sink of the handle's character layers: receives the text the reference prints to stdout from its character
+ * layer ("phasing detected", "START OF MESSAGE", "line added: ...", "END OF MESSAGE", ...: receiver/nav_b_sm.C), chain by
+ * chain as launches are collected, on the collecting thread (for launches of many chains: on the character layer's
+ * worker threads, concurrently).  NULL turns it off.  The singleton of section A prints it to stdout when
+ * NAVTEX_AMD_TRACE=1.                                                                                                 */
+typedef void (*nvx_trace_fn)(void *user, const char *text);
+NVX_API int  nvx_set_trace(nvx_handle *h, nvx_trace_fn fn, void *user);
 /* zero all carried DSP state (FIR histories, demodulator, character layer)  */
 NVX_API int  nvx_reset(nvx_handle *h);
 

@@ -57,6 +57,7 @@ def _load() -> C.CDLL:
     sig = {
         "nvx_last_error": (C.c_char_p, []), "nvx_version": (C.c_char_p, []),
         "init_fir_filter1": (None, []), "sample_in_1": (None, [C.c_double, C.c_double]), "init_fir2_wrapper": (None, []),
+        "nvx_set_trace": (i, [vp, SITOR_TRACE_FN, vp]),
         "nvx_shim_latency": (i, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i]),
         "nvx_shim_flush": (i, []), "nvx_shim_bits": (sz, [i, C.c_char_p, sz]),
         "nvx_StreamACallback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),

@@ -621,6 +621,14 @@ static void deliver_outbox(nvx_handle *h, int stream, Slot &s)
     s.outbox.clear();
 }
 
+extern "C" int nvx_set_trace(nvx_handle *h, nvx_sitor_trace_fn fn, void *user)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (auto &s : h->slots) if (s.sitor) nvx_sitor_set_trace(s.sitor, fn, user);
+    return NVX_OK;
+}
+
 extern "C" int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_frame, int n_frames, void *hip_stream)
 {
     if (!h || !d_iq) { nvx_set_error("nvx_process_resident: null argument"); return NVX_ERR_ARG; }

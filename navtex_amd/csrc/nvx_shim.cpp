@@ -77,6 +77,11 @@ static void shim_require(void)
     if (const char *d = getenv("NAVTEX_AMD_DEVICE")) c.device = atoi(d);
     if (nvx_create(&c, &g_shim) != NVX_OK) shim_fatal("cannot create the GPU pipeline");
     { std::lock_guard<std::mutex> lk(g_shim->mu); g_shim->arrival[0] = &g_shim_clock; g_shim->n_arrival++; }
+    // NAVTEX_AMD_TRACE=1: the character layers print what the reference's print to stdout ("phasing detected", "START OF
+    // MESSAGE", "line added: ...", "END OF MESSAGE", "end of emission detected", ...: receiver/nav_b_sm.C), chain by chain as
+    // the frames are decoded -- for a receiver whose operator reads those lines in the journal
+    if (getenv("NAVTEX_AMD_TRACE") && atoi(getenv("NAVTEX_AMD_TRACE")))
+        nvx_set_trace(g_shim, [](void *, const char *text) { fputs(text, stdout); }, nullptr);
     if (!(getenv("NAVTEX_AMD_NO_KEEPER") && atoi(getenv("NAVTEX_AMD_NO_KEEPER")))) {
         g_keeper = std::thread(keeper_loop, g_shim);
         atexit(keeper_stop);                       // joined before the HIP runtime (loaded earlier) tears down

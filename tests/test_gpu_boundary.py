@@ -96,6 +96,40 @@ def test_capture_loop_program_links_and_decodes(nv, tmp_path):
     assert sorted(got) == sorted(rec["messages"])
 
 
+def test_singleton_prints_the_reference_trace_when_asked(nv, tmp_path):
+    """NAVTEX_AMD_TRACE=1: the reference-shaped surface prints what the reference's character layer prints to stdout
+    (receiver/nav_b_sm.C: "phasing detected", "START OF MESSAGE", "line added: ...", "END OF MESSAGE", ...).  With ONE chain
+    carrying traffic (golden cases weak_518, offset_490) the program's output, its own message lines removed, is exactly
+    the character layer's trace on the golden bits -- which tests/test_host_layer.py pins to the compiled reference's stdout;
+    with two carriers the chains' texts come frame by frame and all the reference's landmarks are there.  Off by default."""
+    import re
+    exe = tmp_path / "capt_loop"
+    lib = ROOT / "navtex_amd"
+    subprocess.run(["gcc", "-O2", str(ROOT / "tests" / "harness" / "capt_loop.c"), "-o", str(exe), f"-L{lib}", "-lnavtex_amd",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+
+    def run(case, trace):
+        rec = GOLD["iq"][case]
+        data = tmp_path / f"{case}.bin"
+        pad_to_frame(nv, cases.make_iq(nv, rec["spec"])).tofile(data)
+        env = dict(os.environ, NAVTEX_AMD_TRACE="1") if trace else {k: v for k, v in os.environ.items() if k != "NAVTEX_AMD_TRACE"}
+        return rec, subprocess.run([str(exe), str(data)], check=True, capture_output=True, text=True, timeout=300, env=env).stdout
+
+    for case, tag, freq in (("weak_518", "bits518", 518), ("offset_490", "bits490", 490)):
+        rec, out = run(case, True)
+        s = nv.Sitor(freq, trace=True)
+        s.feed(rec[tag])
+        want = s.trace()
+        got = re.sub(r"(?m)^\d+\|[^\n]*\n", "", out)            # without the program's own "freq|bbbb|text" lines
+        # (the program's input is padded with silence to a whole frame: a few more idle bytes may follow the golden bits')
+        assert "phasing detected" in want and got.startswith(want) and set(got[len(want):]) <= set(".;*\n "), case
+    rec, out = run("two_carrier", True)
+    for landmark in ("phasing detected", "START OF MESSAGE", "line added", "END OF MESSAGE"):
+        assert out.count(landmark) >= 2, landmark
+    _rec, quiet = run("two_carrier", False)
+    assert "phasing detected" not in quiet and re.sub(r"(?m)^\d+\|[^\n]*\n", "", quiet) == ""
+
+
 def test_poll_takes_in_finished_work_without_waiting(nv, oracle):
     """nvx_poll: results of launches that have finished reach the host (bits, messages) without a fetch, a flush or a
     further launch; a poll right behind a launch returns at once whether or not the GPU is done."""
