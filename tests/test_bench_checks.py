@@ -96,9 +96,10 @@ def test_self_launch_passes_a_signal_on_to_its_ranks(tmp_path):
                    f"bench.self_launch(argparse.Namespace(gpus=2), script={str(worker)!r}, argv=[{str(tmp_path)!r}])\n")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.Popen([sys.executable, str(drv)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    t0 = time.time()
-    while time.time() - t0 < 60 and not ((tmp_path / "pid0").exists() and (tmp_path / "pid1").exists()):
+    t0 = time.time()                              # (the first `import torch` of a fresh container can take a minute or two)
+    while time.time() - t0 < 300 and p.poll() is None and not ((tmp_path / "pid0").exists() and (tmp_path / "pid1").exists()):
         time.sleep(0.2)
+    assert p.poll() is None, p.stderr.read().decode()[-2000:]
     pids = [int((tmp_path / f"pid{r}").read_text()) for r in (0, 1)]
     p.send_signal(signal.SIGTERM)
     assert p.wait(timeout=30) == 128 + signal.SIGTERM
