@@ -72,9 +72,10 @@ int add_message(char *bbbb, char *message, int freq);
 
 /* Drains whatever the push surface has buffered so far in whole frames and
  * waits for the GPU (the reference has no equivalent: it never terminates).
- * Results of launched frames reach add_message without it: with the next
- * launch, or within ~50 ms through the singleton's housekeeping thread
- * (nvx_poll).  What only this call delivers is the tail of a capture that
+ * Results of launched frames reach add_message without it: a few ms after the
+ * sample that completed their frame, through the singleton's housekeeping
+ * thread (nvx_poll every 2 ms while a launch is in flight, every 50 ms
+ * otherwise; nvx_shim_latency reports the figure).  What only this call delivers is the tail of a capture that
  * STOPS: samples sit in the singleton's 4096-sample buffer and in frames not
  * yet complete (up to 0.32 s of signal); a program that ends a capture calls
  * it once, an endless receiver (capt_sched.c:618-621) never needs to.       */
@@ -244,9 +245,10 @@ NVX_API int nvx_stream_stats(nvx_handle *h, int stream, int *active, uint64_t *f
 NVX_API int nvx_flush(nvx_handle *h);
 /* Take in whatever launched work has ALREADY finished -- bits appended, character layer run, messages delivered on
  * the calling thread -- and return at once; never waits for the GPU.  Results otherwise reach the host with the next
- * launch, flush or fetch; a caller with a loop of its own (the capture ring's consumer does this every 50 ms, the
- * singleton of section A on a housekeeping thread) calls this so that the last message before a quiet spell is not
- * held back until signal arrives again.                                                                           */
+ * push (every nvx_push_* takes in finished work on its way out), launch, flush or fetch; a caller with a loop of its own
+ * (the capture ring's consumer and the housekeeping thread of section A's singleton do this on every wake: 2 ms apart
+ * while a launch is in flight, 50 ms otherwise) calls this so that the last message before a quiet spell is not held back
+ * until signal arrives again.                                                                                       */
 NVX_API int nvx_poll(nvx_handle *h);
 /* copy out and consume decoded bits ('B'/'Y') of one chain; returns count.
  * The receiver runs unattended for weeks (main(), receiver/capt_sched.c:558, and its
