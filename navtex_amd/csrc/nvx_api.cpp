@@ -503,6 +503,12 @@ int nvx_launches_in_flight(nvx_handle *h)
     return (int)(h->launched - h->collected);
 }
 
+uint64_t nvx_launch_count(nvx_handle *h)
+{
+    std::lock_guard<std::mutex> lk(h->mu);
+    return h->launched;
+}
+
 extern "C" int nvx_poll(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;

@@ -224,6 +224,8 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto = UINT64_MAX);
 int nvx_collect_ready_locked(nvx_handle *h);
 // launches whose results have not been taken in yet (takes the handle's lock)
 int nvx_launches_in_flight(nvx_handle *h);
+// launches sent on their way since create (takes the handle's lock)
+uint64_t nvx_launch_count(nvx_handle *h);
 // bit-period transition tables of the demodulator FSM (nvx_fsm.h), NVX_FSM_TABLE_ALLOC entries
 const uint32_t *nvx_fsm_table_host();
 

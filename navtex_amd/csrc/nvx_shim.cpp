@@ -44,6 +44,7 @@ static void shim_fatal(const char *what)
 static std::thread g_keeper;
 static std::atomic<bool> g_keeper_stop{ false };
 static std::mutex g_keeper_mu; static std::condition_variable g_keeper_cv;
+static bool g_keeper_kick = false;               // (under g_keeper_mu) a push has sent a launch on its way: look now
 static void keeper_stop(void)
 {
     { std::lock_guard<std::mutex> lk(g_keeper_mu); g_keeper_stop.store(true); }
@@ -60,7 +61,8 @@ static void keeper_loop(nvx_handle *h)
         const int wait_ms = nvx_launches_in_flight(h) ? 2 : 50;
         lk.lock();
         if (g_keeper_stop.load()) break;
-        g_keeper_cv.wait_for(lk, std::chrono::milliseconds(wait_ms));
+        g_keeper_cv.wait_for(lk, std::chrono::milliseconds(wait_ms), [] { return g_keeper_stop.load() || g_keeper_kick; });
+        g_keeper_kick = false;
         if (g_keeper_stop.load()) break;
         lk.unlock();
         if (nvx_poll(h) != NVX_OK) { fprintf(stderr, "navtex_amd: housekeeping: %s\n", nvx_last_error()); lk.lock(); break; }
@@ -92,7 +94,13 @@ static void shim_require(void)
 // (asleep it would notice up to 50 ms later: the latency of this surface was wherever its wake-ups happened to fall)
 static void shim_wake_keeper(void)
 {
-    if (g_keeper.joinable() && nvx_launches_in_flight(g_shim) > 0) g_keeper_cv.notify_one();
+    static uint64_t seen = 0;                    // (one caller thread at a time: the reference's contract, and g_shim_mu)
+    if (!g_keeper.joinable()) return;
+    const uint64_t launched = nvx_launch_count(g_shim);
+    if (launched == seen) return;                // one kick per launch: a file replayed at full speed pushes 25 000 times a second
+    seen = launched;
+    { std::lock_guard<std::mutex> lk(g_keeper_mu); g_keeper_kick = true; }          // (a flag, so that a kick between the keeper's look and its wait is not lost)
+    g_keeper_cv.notify_one();
 }
 
 static void shim_drain(void)
