@@ -560,7 +560,7 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
                            f"{1 + passes} passes over the same frames, state carried)"}
 
 
-def leg_live_latency(nv, ob, signals, device, seconds=6.0):
+def leg_live_latency(nv, ob, signals, device, seconds=8.0):
     """The live path's latency (the loop it replaces decodes synchronously per sample and calls add_message inline:
     receiver/capt_sched.c:484-528 with its 50 ms poll, receiver/nav_b_sm.C:87).  Two capture rings -- one handle fed at
     252 kS/s as the SDRplay callback delivers it, one at the ADC rate 2.016 MS/s -- each fed by a fake-SDR thread AT THE
