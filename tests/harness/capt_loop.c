@@ -87,7 +87,7 @@ int main(int argc, char **argv)
     fclose(in);
     free(ring.slot);
     /* "noflush": what an unmodified capt_sched.c does -- it never flushes.  The messages of every launched frame must
-     * still reach add_message (the library's housekeeping takes finished work in every 50 ms); give it a moment. */
+     * still reach add_message (the library's housekeeping takes finished work in: 2 ms after a launch went out, every 50 ms otherwise); give it a moment. */
     if (argc > 2 && !strcmp(argv[2], "noflush")) { usleep(1500000); return 0; }
     return nvx_shim_flush() == 0 ? 0 : 1;
 }
