@@ -195,6 +195,12 @@ typedef struct nvx_config {
                               /*   76 dB of alias rejection, 14 samples of carried history, ~8 % more kernel time.    */
                               /* Both are build-owned integer definitions (the reference starts at 252 kS/s:          */
                               /* receiver/capt_sched.c:31-34); anything else is NVX_ERR_ARG.                           */
+    int      eager_launch;    /* push_mode = 1 only.  0: a launch goes out when EVERY active stream has a whole frame  */
+                              /*   (fewest, largest launches: thousands of host-fed streams).  1: as soon as ANY        */
+                              /*   stream has one, with the streams that have -- for a handful of free-running radios,  */
+                              /*   whose frames complete at different moments: nobody's bits wait for the slowest       */
+                              /*   radio's frame (up to 0.32 s otherwise).  The streams are independent receivers       */
+                              /*   either way (receiver/decoder.h:31-60, receiver/nav_b_sm.h:92-114): same bits.        */
 } nvx_config;
 
 /* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the

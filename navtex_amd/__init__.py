@@ -184,12 +184,14 @@ class Pipeline(HandleStats):
     def __init__(self, n_streams: int = 1, raw_rate: bool = False, chain_mask: int = CHAIN_518 | CHAIN_490,
                  chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None,
                  max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0,
-                 wideband: bool = False, bit_history: int = 0, store: "Optional[Store]" = None, stage0_order: int = 1):
+                 wideband: bool = False, bit_history: int = 0, store: "Optional[Store]" = None, stage0_order: int = 1,
+                 eager_launch: bool = False):
         self.messages: List[Tuple[int, int, str, str]] = []          # (stream, freq, bbbb, text)
         cfg = N.Config()
         lib.nvx_config_default(C.byref(cfg))
         cfg.device, cfg.n_streams, cfg.raw_rate = device, n_streams, int(raw_rate)
         cfg.stage0_order = int(stage0_order)
+        cfg.eager_launch = int(eager_launch)
         cfg.chain_mask, cfg.max_frames, cfg.char_layer, cfg.push_mode = chain_mask, max_frames, int(char_layer), int(push_mode)
         cfg.wideband = int(wideband)
         cfg.bit_history = int(bit_history)

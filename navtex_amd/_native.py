@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("bit_history", C.c_int),
         ("host_threads", C.c_int),
         ("stage0_order", C.c_int),
+        ("eager_launch", C.c_int),
     ]
 
 

@@ -20,6 +20,10 @@ static int n_whole_frames(const nvx_handle *h, int s) { return (int)(h->fill[s] 
 static bool lockstep_ready(const nvx_handle *h)
 {
     bool any = false;
+    if (h->cfg.eager_launch) {                       // cfg.eager_launch: whoever has a whole frame goes now (a handful of free-running radios)
+        for (int s = 0; s < h->n_in; s++) if (h->fill[s] >= h->frame_in) return true;
+        return false;
+    }
     const int64_t now = nvx_now_ns();
     for (int s = 0; s < h->n_in; s++) {
         if (!h->active[s]) continue;

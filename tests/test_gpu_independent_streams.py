@@ -454,3 +454,34 @@ def test_a_stream_fed_directly_that_goes_quiet_is_not_waited_for(nv, oracle):
             ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(iqs[s])
             assert p.bits(s, 0) == ref.bits(0) and len(ref.bits(0)) > 300, s
         assert p.integrity_stats()[:2] == (0, 0)
+
+
+@pytest.mark.parametrize("eager", [False, True], ids=["lockstep", "eager"])
+def test_free_running_radios_need_not_wait_for_each_others_frames(nv, oracle, eager):
+    """Two radios on one handle, started half a frame apart (free-running SDR clocks: their frames never complete at the
+    same moment), fed at the real rate through a capture ring each.  Lock-step launches (the default: fewest, largest
+    launches) make the earlier radio's bits wait for the later radio's frame -- about 160 ms here --; with
+    cfg.eager_launch a launch goes out as soon as ANY stream has a whole frame, and both radios' frames are decoded and
+    delivered within milliseconds.  Same bits either way: the streams are independent receivers."""
+    import time
+    from fake_sdr import FakeSdr
+    n_frames = 8
+    iqs = [nv.synth_host(signals.stream_params(nv, 8300 + s, nv.RATE_IN)[0], nv.RATE_IN, n_frames * nv.FRAME_IN) for s in range(2)]
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=False, eager_launch=eager) as p:
+        caps = [nv.Capture(p, s, ring_seconds=2.0) for s in range(2)]
+        sdrs = [FakeSdr(caps[s], iqs[s], nv.RATE_IN, nv.FRAME_IN, seed=20 + s, packet=(150, 420)) for s in range(2)]
+        sdrs[0].start(); time.sleep(0.16); sdrs[1].start()          # radio 1 runs half a frame behind radio 0
+        for t in sdrs: t.join()
+        time.sleep(0.1)
+        lat = [c.latency() for c in caps]
+        stats = [c.stats() for c in caps]
+        partial = p.stream_stats(0)[2]
+        for c in caps: c.stop()
+        for s in range(2):
+            ref = oracle.Pipe(chain_mask=1, charlayer=False); ref.push(iqs[s])
+            assert p.bits(s, 0) == ref.bits(0) and stats[s][1] == 0 and lat[s]["frames"] >= n_frames - 1, s
+        assert max(t.late_ms for t in sdrs) < 50.0
+        if eager:
+            assert lat[0]["max_ms"] < 50.0 and lat[1]["max_ms"] < 50.0 and partial > 0, (lat, partial)
+        else:
+            assert lat[0]["p50_ms"] > 100.0 and lat[1]["p50_ms"] < 50.0, lat          # the premise: the early radio waits for the late one's frame
