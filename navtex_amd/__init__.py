@@ -243,6 +243,11 @@ class Pipeline(HandleStats):
         N.check(lib.nvx_stream_stats(self._h, stream, C.byref(a), C.byref(f), C.byref(p)), "nvx_stream_stats")
         return bool(a.value), f.value, p.value
 
+    def set_trace(self, on_text: Optional[Callable[[str], None]]) -> None:
+        """Route the character layers' trace (what the reference prints to stdout: nav_b_sm.C) to on_text, or turn it off (None)."""
+        self._trace_cb = N.SITOR_TRACE_FN(lambda u, t: on_text(t.decode("latin1"))) if on_text else C.cast(None, N.SITOR_TRACE_FN)
+        N.check(lib.nvx_set_trace(self._h, self._trace_cb, None), "nvx_set_trace")
+
     def decode_wav(self, path: str, stream: int = 0) -> int:
         return N.check(lib.nvx_decode_wav(self._h, stream, path.encode()), "nvx_decode_wav")
 

@@ -96,6 +96,24 @@ def test_capture_loop_program_links_and_decodes(nv, tmp_path):
     assert sorted(got) == sorted(rec["messages"])
 
 
+def test_set_trace_on_a_handle_delivers_the_character_layers_text(nv):
+    """nvx_set_trace: the text the reference's character layer prints (receiver/nav_b_sm.C) for the handle's chains, as the
+    launches are collected -- equal to the stand-alone character layer's trace on the same bits; NULL turns it off."""
+    rec = GOLD["iq"]["weak_518"]
+    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    text = []
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=3, push_mode=True, char_layer=True) as p:
+        p.set_trace(text.append)
+        half = (len(iq) // nv.FRAME_IN // 2) * nv.FRAME_IN
+        p.push(0, iq[:half]); p.flush()
+        n_half = len("".join(text))
+        p.set_trace(None)
+        p.push(0, iq[half:]); p.flush()
+        assert len("".join(text)) == n_half and n_half > 0          # nothing more once it is off
+        s = nv.Sitor(518, trace=True); s.feed(p.bits(0, 0))
+        assert s.trace().startswith("".join(text)) and "phasing detected" in "".join(text)
+
+
 def test_singleton_prints_the_reference_trace_when_asked(nv, tmp_path):
     """NAVTEX_AMD_TRACE=1: the reference-shaped surface prints what the reference's character layer prints to stdout
     (receiver/nav_b_sm.C: "phasing detected", "START OF MESSAGE", "line added: ...", "END OF MESSAGE", ...).  With ONE chain
