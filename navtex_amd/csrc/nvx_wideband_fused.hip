@@ -9,16 +9,17 @@
 //
 // Mapping.  A work unit = one frame (315 passes) of one wideband stream, pulled from the same kind of atomic queue as
 // the cascade kernel's; a workgroup = 8 waves, wave k owns sub-band k (its polyphase window, mixer / FIR2 buffers and
-// histories: one CascadeLds<2> each, 8 x 17.4 KB) and the workgroup shares one raw window (40 halo + 2048 samples).
+// histories: one CascadeLds<2, false> each, 8 x 12.0 KB -- r4: the waves end at FIR2, FIR3 is nvx_fir3.hip) and the workgroup
+// shares one raw window (40 halo + 2048 samples).
 // A pass = 256 channeliser output instants = 2048 raw samples = 8 KiB:
 //   1. every wave stores its prefetched 1-KiB piece into the raw window and requests the next pass's piece   | barrier
 //   2. every wave channelises 32 instants (a lane pair per instant, one component each) and writes the eight
 //      sub-band samples of every instant, as fp64, into the eight windows                                     | barrier
-//   3. every wave runs one cascade pass on its own window (CascadeWave<2>::compute_pass)
+//   3. every wave runs one cascade pass on its own window (CascadeWave<2, false>::compute_pass: FIR1, mixers, FIR2 -> y2 row in HBM)
 // Two workgroup barriers per pass.  Filter histories and the 40-sample halo travel from unit (w, f) to (w, f+1)
 // through HBM exactly as in the cascade kernel: sc1 accesses, every storing wave drains (vmcnt 0), workgroup
 // barrier, one lane sets done[w]; the consumer's lane 0 polls, workgroup barrier, sc1 loads (MI355X_MICROARCH.md,
-// "Valid forms", first row).  The grid is one workgroup per CU (LDS: 151 KB).
+// "Valid forms", first row).  The grid is one workgroup per CU (LDS: 104 KB; 187 VGPRs: two waves per SIMD).
 // Few streams (r3): with fewer wideband streams than resident workgroups -- the physically real case is ONE RSP's
 // 2.016 MS/s capture replayed from a recording, receiver/capt_sched.c:356-417 -- the frames of a stream would run one
 // after the other on 1 of 256 CUs.  The launcher then makes the units INDEPENDENT, as the cascade kernel does
