@@ -46,6 +46,43 @@ def test_header_compiles_as_plain_c(tmp_path):
                    check=True)
 
 
+def test_the_c_snippets_of_integration_md_compile(tmp_path):
+    """Every ```c block of INTEGRATION.md that is a complete statement sequence compiles as C99 against the header (-Wall
+    -Werror), wrapped in a function with the variables the text assumes: a maintainer pastes these."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    blocks = re.findall(r"```c\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 5
+    prelude = """
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
+#include "navtex_amd.h"
+typedef void (*sdrplay_api_StreamCallback_t)(short *, short *, void *, unsigned int, unsigned int, void *);
+struct { sdrplay_api_StreamCallback_t StreamACbFn; } cbFns;
+struct { void *dev; } dev0, *chosenDevice = &dev0;
+static void sdrplay_api_Init(void *d, void *fns, void *ctx) { (void)d; (void)fns; (void)ctx; }
+static void die(const char *m) { fputs(m, stderr); exit(1); }
+static void my_sink(void *u, int s, const char *b, const char *m, int f) { (void)u; (void)s; (void)b; (void)m; (void)f; }
+static const void *upload(int dev, int first, int n) { (void)dev; (void)first; (void)n; return 0; }
+"""
+    compiled = 0
+    for i, b in enumerate(blocks):
+        if "nvx_" not in b or "#cgo" in b:
+            continue
+        body = b.replace("...", "").replace("#include \"navtex_amd.h\"", "")
+        src = tmp_path / f"snip{i}.c"
+        src.write_text(prelude + "void snippet(nvx_handle *handle, nvx_handle *h, nvx_capture *cap, void *d_iq, size_t pitch_samples, size_t pitch, int dev, int n_wide, int F,\n"
+                       "             void *d_raw, void *d_sub, size_t pitch_raw, size_t pitch_sub, void *hist_in, void *hist_out, char *buf, size_t buf_cap) {\n"
+                       "  (void)d_iq; (void)handle; (void)h; (void)cap; (void)pitch_samples; (void)pitch; (void)dev; (void)n_wide; (void)F;\n"
+                       "  (void)d_raw; (void)d_sub; (void)pitch_raw; (void)pitch_sub; (void)hist_in; (void)hist_out; (void)buf; (void)buf_cap;\n"
+                       "  {\n" + body + "\n  }\n}\n")
+        r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-function", "-Wno-shadow",
+                            f"-I{ROOT / 'include'}", "-c", str(src), "-o", str(tmp_path / f"snip{i}.o")], capture_output=True, text=True)
+        assert r.returncode == 0, f"INTEGRATION.md c block {i}:\n{b}\n{r.stderr[-1500:]}"
+        compiled += 1
+    assert compiled >= 4
+
+
 def test_links_against_a_c_program_with_its_own_add_message(nv, tmp_path):
     """The drop-in claim at link level: a C program that defines add_message (as the
     receiver's message_store.o does) and calls the three reference symbols links against
