@@ -477,12 +477,11 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
         p.close()
         ok = ok and ok_after
         sub_samples = 8 * W * n_sub
-        fused = os.environ.get("NVX_WB_FUSED", "1") != "0"
-        fps = flops_per_sample(2, fir3_inside=not fused)
+        fps = flops_per_sample(2, fir3_inside=False)      # the fused kernel's waves end at FIR2: nvx_fir3 does the rest
         tops = fps * sub_samples / (c_ms * 1e-3) / 1e12 if c_ms > 0 else None
         return {"what": f"WIDEBAND: {W} streams x 2.016 MS/s x {F} frames, 16 NAVTEX carriers each (8 sub-bands x 2 chains) = {16 * W} carriers; "
                         "channeliser + two-chain cascades (FIR1, mixers, FIR2) in one kernel, FIR3 in nvx_fir3 beside the next launch; not part of the timed region above",
-                "kernel": "nvx_wideband_fused" if os.environ.get("NVX_WB_FUSED", "1") != "0" else "nvx_channelise + nvx_fir_cascade<252k,2>",
+                "kernel": "nvx_wideband_fused",
                 "steps": steps, "ms_per_step": round(el / steps * 1e3, 3), "value": round(W * n_raw * steps / el / 1e6, 1),
                 "carrier_equivalent_msamples_per_s": round(16 * W * n_raw * steps / el / 1e6, 1),
                 "kernel_avg_launch_ms": round(c_ms, 3), "fir3_avg_launch_ms": round(f3_ms, 3),
@@ -735,7 +734,6 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     pipe.fetch()
     pipe.enable_timing(True); pipe.kernel_time_stats(0, reset=True)
     pipe.wait_stats(reset=True)
-    nv.lib.nvx_channelise_timing(1); nv.channelise_time_stats(reset=True)
     ranks.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -758,13 +756,11 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
     stale_all, seal_failures_all = int(ranks.reduce(float(stale), "sum")), int(ranks.reduce(float(seal_failures), "sum"))
     casc_ms, n_l = pipe.kernel_time_stats(0)
     dem_ms, _ = pipe.kernel_time_stats(1)
-    ch_ms, n_c = nv.channelise_time_stats()
     w_polls, w_units, w_launches = pipe.wait_stats()
-    casc_avg, ch_avg = casc_ms / max(n_l, 1), ch_ms / max(n_c, 1)
-    fused = n_c == 0                                # the fused kernel has no separate channeliser launch
+    casc_avg = casc_ms / max(n_l, 1)
     f3_avg = fir3_avg_ms(pipe, n_l)
     sub_samples = 8 * W * n_sub
-    fps = flops_per_sample(2, fir3_inside=not fused)  # the fused kernel's waves end at FIR2: nvx_fir3 does the rest
+    fps = flops_per_sample(2, fir3_inside=False)      # the fused kernel's waves end at FIR2: nvx_fir3 does the rest
     tops = fps * sub_samples / (casc_avg * 1e-3) / 1e12 if casc_avg else None
     line = {
         "metric": "IQ Msamples/s through FIR->FSK->bitsync", "value": round(world * W * n_raw * args.steps / elapsed / 1e6, 1),
@@ -776,21 +772,19 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                    "parallelism": f"wideband streams sharded {world} ways, no collective"},
         "carriers_decoded": 16 * W * world,
         "carrier_equivalent_msamples_per_s": round(16 * world * W * n_raw * args.steps / elapsed / 1e6, 1),
-        "roofline": {"bound": "fp64_valu", "kernel": "nvx_wideband_fused (channeliser + 8 x two-chain cascade up to FIR2; FIR3 = nvx_fir3)" if fused else "nvx_fir_cascade<252k,2>",
+        "roofline": {"bound": "fp64_valu", "kernel": "nvx_wideband_fused (channeliser + 8 x two-chain cascade up to FIR2; FIR3 = nvx_fir3)",
                      "fir3_avg_launch_ms": round(f3_avg, 3),
                      "achieved": round(tops, 2) if tops else None,
                      "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
                      "traffic": None, "flop_per_sample": round(fps, 2), "samples_per_launch": sub_samples,
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
-                     "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F * (1 if n_c == 0 else 8)), 4),
+                     "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F ), 4),
                                  "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1),
                                  "stale_detected": stale_all, "launches_failed_integrity": seal_failures_all},
                      "algorithmic_bytes_per_launch": W * n_raw * 4,
                      "note": "exact mul-then-add fp64 (no FMA): the roof is the fp64 issue rate at 2.4 GHz, 256 CUs x 4 SIMDs x 16 lanes; "
                              "only the cascade's fp64 operations are counted, the channeliser's integer work rides on top"},
-        "channeliser": None if fused else {"kernel": "nvx_channelise", "avg_launch_ms": round(ch_avg, 3), "launches": int(n_c),
-                        "read_plus_write_gbs": round((W * n_raw * 4 + sub_samples * 4) / (ch_avg * 1e-3) / 1e9, 1) if ch_avg else None},
-        "form": "fused (one kernel, sub-bands stay in LDS)" if fused else "two kernels (NVX_WB_FUSED=0)",
+        "form": "fused (one kernel, sub-bands stay in LDS)",
         "cpu_baseline": cpu, "parity": parity, "parity_streams_checked": checked, "parity_after_timed": parity_after,
         "parity_after_timed_streams": int(ranks.reduce(16.0 * nw_after, "sum")), "parity_after_timed_launches": args.warmup + args.steps,
         "demod": {"near_ties": near_ties},

@@ -31,7 +31,7 @@ enum {
     NVX_ERR_NOMEM   = -4,
     NVX_ERR_STATE   = -5,   /* call not valid in the handle's current mode       */
     NVX_ERR_IO      = -6,   /* file errors of the WAV path                       */
-    NVX_ERR_FULL    = -7    /* staging ring cannot take the samples              */
+    NVX_ERR_FULL    = -7    /* (no longer returned: the streams of a handle launch independently) */
 };
 NVX_API const char *nvx_last_error(void);
 NVX_API const char *nvx_version(void);
@@ -80,6 +80,11 @@ int add_message(char *bbbb, char *message, int freq);
  * yet complete (up to 0.32 s of signal); a program that ends a capture calls
  * it once, an endless receiver (capt_sched.c:618-621) never needs to.       */
 NVX_API int nvx_shim_flush(void);
+/* END of the input (a file replayed through sample_in_1, a capture that is over): nvx_shim_flush, then the last,
+ * partial frame at its true length -- nvx_finish of section C on the singleton.  Afterwards the singleton has decoded
+ * exactly the bits the reference's objects have decoded when capt_sched.c's loop (:509-513) has handed them the same
+ * samples and stopped.  init_fir_filter1 starts a new stream.                                                        */
+NVX_API int nvx_shim_finish(void);
 /* Decode latency of this surface, per frame of 0.32 s: from the entry of the sample_in_1 call (or singleton stream
  * callback) that carried the frame's last sample to its bits being pollable and its messages delivered to
  * add_message -- booked as nvx_capture_latency books a capture ring's (section B').  The reference decodes inline
@@ -128,18 +133,17 @@ NVX_API void nvx_capture_callback(short *xi, short *xq, void *params, unsigned i
 NVX_API int  nvx_capture_stop(nvx_capture *c);
 /* complex samples offered by the producer / dropped on overrun / handed to the GPU pipeline */
 NVX_API void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *dropped, uint64_t *consumed);
-/* Health of the consumer while it runs: returns the error that stopped it (NVX_OK while it is alive; a HIP failure is
- * the only thing that stops it early) and, optionally, how often it met back-pressure (NVX_ERR_FULL from the handle).
- * Since round 3 the streams of a handle advance independently (section C, "stream independence"), so another stream's
- * stall no longer produces back-pressure; only a wideband handle in its two-kernel A/B form (NVX_WB_FUSED=0) still
- * launches all streams together and can report it.                                                                 */
-NVX_API int  nvx_capture_error(nvx_capture *c, uint64_t *full_waits);
+/* Health of the consumer while it runs: the error that stopped it (NVX_OK while it is alive; a failed launch or HIP
+ * call is the only thing that stops it early).  The streams of a handle advance independently (section C, "stream
+ * independence"), so another stream's stall produces no back-pressure.                                              */
+NVX_API int  nvx_capture_error(nvx_capture *c);
 /* Silent-radio detection.  The reference has one radio and only prints sdrplay_api_DeviceRemoved when it disappears
  * (receiver/capt_sched.c:210-212).  With several radios on one handle a silent one must not hold the others: when the
  * consumer has handed on no sample for the stall timeout (default 2 s; <= 0 disables), it marks its stream INACTIVE
  * (nvx_stream_set_active) -- launches stop waiting for it -- and counts the event.  nvx_capture_stalled returns 1
  * while the stream is marked silent, 0 otherwise (negative: error); the first sample that arrives afterwards makes
- * the stream active again and it continues bit-exactly from its own carried state.                                */
+ * the stream active again and it continues bit-exactly from its own carried state.  The ring's timeout also becomes
+ * its stream's push-level timeout (nvx_config.stall_timeout_ms), so one figure governs how long the others wait.  */
 NVX_API int  nvx_capture_stalled(nvx_capture *c, uint64_t *stall_events);
 NVX_API void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds);
 /* Decode latency of the live path.  The reference decodes synchronously per sample and calls add_message inline
@@ -201,6 +205,9 @@ typedef struct nvx_config {
                               /*   whose frames complete at different moments: nobody's bits wait for the slowest       */
                               /*   radio's frame (up to 0.32 s otherwise).  The streams are independent receivers       */
                               /*   either way (receiver/decoder.h:31-60, receiver/nav_b_sm.h:92-114): same bits.        */
+    int      stall_timeout_ms;/* push_mode = 1 only.  A stream that has delivered nothing for this long is not waited  */
+                              /*   for by the others' launches (0: the default, 2000; < 0: waited for for ever).  Its   */
+                              /*   next push counts again at once.                                                     */
 } nvx_config;
 
 /* Callbacks (on_message) run on the thread that calls nvx_flush / nvx_fetch_bits / nvx_push_* with the
@@ -229,11 +236,10 @@ NVX_API int  nvx_reset(nvx_handle *h);
  * frames) before that, the launch goes out with the streams that HAVE a frame,
  * each carrying its own filter / demodulator state -- a stalled or slower
  * radio never blocks the others, and rejoins later bit-exactly.  A stream
- * that has delivered nothing for 2 s (no capture ring needed: the handle keeps
- * the time of every stream's last push) is not waited for either, so the
- * others keep launching frame by frame; its next push counts again at once.
- * Returns NVX_OK (NVX_ERR_FULL only from a wideband handle in its two-kernel
- * form).
+ * that has delivered nothing for 2 s (nvx_config.stall_timeout_ms; no capture
+ * ring needed: the handle keeps the time of every stream's last push) is not
+ * waited for either, so the others keep launching frame by frame; its next
+ * push counts again at once.
  * Threads: any number of threads may push into one handle, ONE per stream at
  * a time (a second pusher of the same stream waits until the first one's call
  * has returned: a push call is atomic against other pushes of its stream).  Pushes of 128 KB and
@@ -247,8 +253,21 @@ NVX_API int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const 
  * and how many launches of the handle covered only some of its streams (any out pointer may be NULL).           */
 NVX_API int nvx_stream_set_active(nvx_handle *h, int stream, int active);
 NVX_API int nvx_stream_stats(nvx_handle *h, int stream, int *active, uint64_t *frames_done, uint64_t *partial_launches);
-/* wait for all launched work, deliver bits/messages                          */
+/* launch whatever is staged in WHOLE frames, wait for all launched work, deliver bits/messages.  A partial frame stays
+ * staged: the stream goes on bit-exactly with the next push.                                                        */
 NVX_API int nvx_flush(nvx_handle *h);
+/* END of the input.  The reference's loop hands every sample it is given to sample_in_1 and stops
+ * (receiver/capt_sched.c:509-513): its decoder has then seen floor(n / 280) samples at 900 S/s and has decided exactly
+ * the bits those samples decide (receiver/decoder.C:73-137).  nvx_finish does the same for every stream of a push-mode
+ * handle: nvx_flush, then ONE more launch for the streams that still hold a partial frame, each at its TRUE length --
+ * the demodulator stops at the stream's last real 900 S/s sample (floor(n / 280) at 252 kS/s input, floor(n / 2240) at
+ * 2.016 MS/s); no padding is decoded, no bit is withheld: the bits of a stream are then exactly the reference's on the
+ * same samples, whatever the length.  A stream that held a partial frame is ENDED afterwards (its filters have run
+ * past its last sample): nvx_push_* and launches that name it return NVX_ERR_STATE until nvx_reset.  Streams that
+ * ended on a frame boundary are not affected.  nvx_stream_finish: the same for one stream (the whole frames of the
+ * others are launched as by nvx_flush).                                                                            */
+NVX_API int nvx_finish(nvx_handle *h);
+NVX_API int nvx_stream_finish(nvx_handle *h, int stream);
 /* Take in whatever launched work has ALREADY finished -- bits appended, character layer run, messages delivered on
  * the calling thread -- and return at once; never waits for the GPU.  Results otherwise reach the host with the next
  * push (every nvx_push_* takes in finished work on its way out), launch, flush or fetch; a caller with a loop of its own
@@ -300,7 +319,9 @@ NVX_API int   nvx_cascade_wait_stats(nvx_handle *h, uint64_t *polls, uint64_t *u
  * block carries a 64-bit word over its contents and its position; a unit recomputes it over what it loaded.
  * stale_repaired: hand-overs INSIDE a launch whose block failed the check -- the unit rebuilt its histories from its
  * own input instead (bit-identical results) -- expected 0; launch_failures: launches whose inherited state failed the
- * check (the call that collects such a launch returns NVX_ERR_HIP and its bits are discarded; nvx_reset recovers);
+ * check.  Such a failure STICKS: the call that collects the launch returns NVX_ERR_HIP, its bits and those of every
+ * launch queued behind it are discarded (what the device carries from there on was computed from the bad block), and
+ * every later push, launch, flush, poll and fetch returns NVX_ERR_STATE until nvx_reset;
  * launches: launches collected so far (as nvx_cascade_wait_stats).  reset != 0 clears the two counters afterwards. */
 NVX_API int   nvx_cascade_integrity_stats(nvx_handle *h, uint64_t *stale_repaired, uint64_t *launch_failures, uint64_t *launches, int reset);
 /* How close the demodulator's bit-timing decisions came to a tie since create / reset.  The arg-max over the nine
@@ -371,6 +392,8 @@ NVX_API int    nvx_group_fetch_bits(nvx_group *g);
 /* host input by global stream id (nvx_push_iq of the owning member; cfg.push_mode) and the matching flush     */
 NVX_API int    nvx_group_push_iq(nvx_group *g, int global_stream, const int16_t *iq_interleaved, size_t n);
 NVX_API int    nvx_group_flush(nvx_group *g);
+/* nvx_finish of every member (end of the input of every stream), then the messages as nvx_group_flush delivers them */
+NVX_API int    nvx_group_finish(nvx_group *g);
 NVX_API size_t nvx_group_poll_bits(nvx_group *g, int global_stream, int chain, char *out, size_t cap);
 NVX_API size_t nvx_group_bit_count(nvx_group *g, int global_stream, int chain);
 /* Bind the CALLING thread to the CPUs of the NUMA node the HIP device hangs off (PCI bus id -> sysfs numa_node /
@@ -417,8 +440,10 @@ NVX_API size_t   nvx_wav_get_sample_size(const nvx_wav *w);             /* wav.h
 NVX_API size_t   nvx_wav_get_length(const nvx_wav *w);                  /* wav.h:217, frames */
 NVX_API const char *nvx_wav_err(void);                                  /* wav.h:114 */
 /* File harness the reference lacks: open -> loop wav_read ->
- * the capt_sched.c:509-513 loop, on the GPU.  The tail is zero-padded to a
- * whole frame.  Returns number of frames processed or a negative error.      */
+ * the capt_sched.c:509-513 loop, on the GPU, ended by nvx_stream_finish: the
+ * bits are the reference's on the same file, whatever its length; the stream is
+ * ended afterwards (nvx_reset starts a new one).  Returns the number of frames
+ * (the last one may be partial) or a negative error.                          */
 NVX_API int nvx_decode_wav(nvx_handle *h, int stream, const char *filename);
 
 /* ==========================================================================

@@ -185,13 +185,14 @@ class Pipeline(HandleStats):
                  chain_masks: Optional[Iterable[int]] = None, labels: Optional[Sequence[Sequence[int]]] = None,
                  max_frames: int = 1, char_layer: bool = True, push_mode: bool = False, device: int = 0,
                  wideband: bool = False, bit_history: int = 0, store: "Optional[Store]" = None, stage0_order: int = 1,
-                 eager_launch: bool = False):
+                 eager_launch: bool = False, stall_timeout_ms: int = 0):
         self.messages: List[Tuple[int, int, str, str]] = []          # (stream, freq, bbbb, text)
         cfg = N.Config()
         lib.nvx_config_default(C.byref(cfg))
         cfg.device, cfg.n_streams, cfg.raw_rate = device, n_streams, int(raw_rate)
         cfg.stage0_order = int(stage0_order)
         cfg.eager_launch = int(eager_launch)
+        cfg.stall_timeout_ms = int(stall_timeout_ms)
         cfg.chain_mask, cfg.max_frames, cfg.char_layer, cfg.push_mode = chain_mask, max_frames, int(char_layer), int(push_mode)
         cfg.wideband = int(wideband)
         cfg.bit_history = int(bit_history)
@@ -228,6 +229,15 @@ class Pipeline(HandleStats):
 
     def flush(self) -> None:
         N.check(lib.nvx_flush(self._h), "nvx_flush")
+
+    def finish(self, stream: Optional[int] = None) -> None:
+        """End of the input (nvx_finish / nvx_stream_finish): flush, then the last, partial frame of every stream (or of
+        `stream`) at its TRUE length -- afterwards the bits are exactly the reference's on the same samples, whatever
+        their number (receiver/capt_sched.c:509-513 stops with its last sample).  Such a stream is ended: reset() starts anew."""
+        if stream is None:
+            N.check(lib.nvx_finish(self._h), "nvx_finish")
+        else:
+            N.check(lib.nvx_stream_finish(self._h, stream), "nvx_stream_finish")
 
     def poll(self) -> None:
         """Take in whatever launched work has already finished; never waits (nvx_poll)."""
@@ -419,6 +429,10 @@ class Group:
 
     def flush(self) -> None:
         N.check(lib.nvx_group_flush(self._g), "nvx_group_flush")
+
+    def finish(self) -> None:
+        """End of every stream's input (nvx_group_finish = nvx_finish of every member)."""
+        N.check(lib.nvx_group_finish(self._g), "nvx_group_finish")
 
     def reset(self) -> None:
         N.check(lib.nvx_group_reset(self._g), "nvx_group_reset")

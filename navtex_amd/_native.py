@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("host_threads", C.c_int),
         ("stage0_order", C.c_int),
         ("eager_launch", C.c_int),
+        ("stall_timeout_ms", C.c_int),
     ]
 
 
@@ -60,7 +61,7 @@ def _load() -> C.CDLL:
         "init_fir_filter1": (None, []), "sample_in_1": (None, [C.c_double, C.c_double]), "init_fir2_wrapper": (None, []),
         "nvx_set_trace": (i, [vp, SITOR_TRACE_FN, vp]),
         "nvx_shim_latency": (i, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i]),
-        "nvx_shim_flush": (i, []), "nvx_shim_bits": (sz, [i, C.c_char_p, sz]),
+        "nvx_shim_flush": (i, []), "nvx_shim_finish": (i, []), "nvx_shim_bits": (sz, [i, C.c_char_p, sz]),
         "nvx_StreamACallback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
         "nvx_capture_start": (i, [vp, i, C.c_double, C.POINTER(vp)]), "nvx_capture_callback": (None, [vp, vp, vp, C.c_uint, C.c_uint, vp]),
         "nvx_capture_latency": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i]),
@@ -72,6 +73,7 @@ def _load() -> C.CDLL:
         "nvx_config_default": (None, [C.POINTER(Config)]),
         "nvx_create": (i, [C.POINTER(Config), C.POINTER(vp)]), "nvx_destroy": (None, [vp]), "nvx_reset": (i, [vp]),
         "nvx_push_iq": (i, [vp, i, vp, sz]), "nvx_push_planar": (i, [vp, i, vp, vp, sz]), "nvx_flush": (i, [vp]),
+        "nvx_finish": (i, [vp]), "nvx_stream_finish": (i, [vp, i]),
         "nvx_poll_bits": (sz, [vp, i, i, C.c_char_p, sz]),
         "nvx_process_resident": (i, [vp, vp, sz, sz, i, vp]), "nvx_fetch_bits": (i, [vp]),
         "nvx_bit_count": (sz, [vp, i, i]),
@@ -80,11 +82,11 @@ def _load() -> C.CDLL:
         "nvx_group_reset": (i, [vp]), "nvx_group_size": (i, [vp]),
         "nvx_group_member": (i, [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(vp)]), "nvx_group_member_of": (i, [vp, i]),
         "nvx_group_process_resident": (i, [vp, C.POINTER(vp), sz, sz, i]), "nvx_group_fetch_bits": (i, [vp]),
-        "nvx_group_push_iq": (i, [vp, i, vp, sz]), "nvx_group_flush": (i, [vp]),
+        "nvx_group_push_iq": (i, [vp, i, vp, sz]), "nvx_group_flush": (i, [vp]), "nvx_group_finish": (i, [vp]),
         "nvx_group_poll_bits": (sz, [vp, i, i, C.c_char_p, sz]), "nvx_group_bit_count": (sz, [vp, i, i]),
         "nvx_bind_thread_to_device": (i, [i]),
         "nvx_demod_tie_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
-        "nvx_capture_error": (i, [vp, C.POINTER(C.c_uint64)]),
+        "nvx_capture_error": (i, [vp]),
         "nvx_capture_stalled": (i, [vp, C.POINTER(C.c_uint64)]), "nvx_capture_set_stall_timeout": (None, [vp, C.c_double]),
         "nvx_stream_set_active": (i, [vp, i, i]), "nvx_poll": (i, [vp]),
         "nvx_stream_stats": (i, [vp, i, C.POINTER(i), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -70,17 +70,10 @@ static void free_handle(nvx_handle *h)
     if (h->launch_done_valid) hipEventSynchronize(h->launch_done);      // the last launch may sit on a caller's stream
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->stream2) hipStreamSynchronize(h->stream2);
-    if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
-    for (int i = 0; i < 2; i++) {
-        hipFree(h->d_sub[i]); hipFree(h->d_whist[i]);
-        if (h->chan_done[i]) hipEventDestroy(h->chan_done[i]);
-        if (h->sub_free[i]) hipEventDestroy(h->sub_free[i]);
-        if (h->in_ready[i]) hipEventDestroy(h->in_ready[i]);
-    }
+    hipFree(h->d_whist[0]); hipFree(h->d_whist[1]);
     hipFree(h->d_y2[0]); hipFree(h->d_y2[1]); hipFree(h->d_y2row);
     hipFree(h->d_masks); hipFree(h->d_active); hipFree(h->d_cstate[0]); hipFree(h->d_cstate[1]); hipFree(h->d_y3[0]); hipFree(h->d_y3[1]);
     for (int i = 0; i < 2; i++) { if (h->casc_done[i]) hipEventDestroy(h->casc_done[i]); if (h->demod_done[i]) hipEventDestroy(h->demod_done[i]); }
-    if (h->fsm_done) hipEventDestroy(h->fsm_done);
     if (h->launch_done) hipEventDestroy(h->launch_done);
     hipFree(h->d_ties); if (h->h_ties) hipHostFree(h->h_ties);
     hipFree(h->d_dd[0]); hipFree(h->d_dd[1]); hipFree(h->d_di); hipFree(h->d_fsm_tab); hipFree(h->d_dphi); hipFree(h->d_in); hipFree(h->d_words); hipFree(h->d_ctrl);
@@ -114,6 +107,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     *out = nullptr;
     if (cfg->stage0_order != 0 && cfg->stage0_order != 1 && cfg->stage0_order != 3) { nvx_set_error("nvx_create: stage0_order %d (1 or 3)", cfg->stage0_order); return NVX_ERR_ARG; }
     if (cfg->stage0_order == 3 && !(cfg->raw_rate && !cfg->wideband)) { nvx_set_error("nvx_create: stage0_order 3 needs raw_rate input (a wideband handle has its channeliser, 252 kS/s input no stage 0)"); return NVX_ERR_ARG; }
+    if (!cfg->push_mode && (cfg->eager_launch || cfg->stall_timeout_ms)) { nvx_set_error("nvx_create: eager_launch / stall_timeout_ms belong to push_mode handles"); return NVX_ERR_ARG; }
     int rc = nvx_select_device(cfg->device);
     if (rc != NVX_OK) return rc;
 
@@ -133,6 +127,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     h->slots.resize(h->n_slots);
     h->parity.assign(h->n_in, 0);
     h->g0s.assign(h->n_in, 0);
+    h->ended.assign(h->n_in, 0);
     h->arrival.assign(h->n_in, nullptr);
     bool any_two = false;
     for (int s = 0; s < h->n_streams; s++) {
@@ -164,7 +159,6 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipEventCreateWithFlags(&h->casc_done[i], hipEventDisableTiming));
         CR_TRY(hipEventCreateWithFlags(&h->demod_done[i], hipEventDisableTiming));
     }
-    CR_TRY(hipEventCreateWithFlags(&h->fsm_done, hipEventDisableTiming));
     CR_TRY(hipEventCreateWithFlags(&h->launch_done, hipEventDisableTiming));
     std::vector<uint8_t> active(h->n_slots);
     for (int i = 0; i < h->n_slots; i++) active[i] = h->slots[i].active;
@@ -174,7 +168,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
     CR_TRY(hipMemcpy(h->d_active, active.data(), h->n_slots, hipMemcpyHostToDevice));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_cstate[i], (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES));
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y3[i], (size_t)h->n_slots * h->y3_cap * sizeof(double2)));
-    if (cfg->wideband && nvx_wb_fused()) {
+    if (cfg->wideband) {
         // the fused wideband kernel's waves end at FIR2: a row of 9 kS/s fp64 pairs per ACTIVE chain, two buffers (nvx_kernels.h)
         std::vector<int> rows(h->n_slots, -1);
         for (int i = 0; i < h->n_slots; i++) if (h->slots[i].active) rows[i] = h->y2_rows++;
@@ -204,16 +198,8 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         CR_TRY(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
         for (int i = 0; i < 8; i++) CR_TRY(hipEventCreate(&r.ev[i]));
     }
-    if (cfg->wideband) {
-        CR_TRY(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            CR_TRY(hipMalloc(&h->d_sub[i], (size_t)h->n_streams * cfg->max_frames * NVX_FRAME_IN * 4));
-            CR_TRY(hipMalloc(&h->d_whist[i], (size_t)h->n_in * 40 * 4));
-            CR_TRY(hipEventCreateWithFlags(&h->chan_done[i], hipEventDisableTiming));
-            CR_TRY(hipEventCreateWithFlags(&h->sub_free[i], hipEventDisableTiming));
-            CR_TRY(hipEventCreateWithFlags(&h->in_ready[i], hipEventDisableTiming));
-        }
-    }
+    if (cfg->wideband)         // the channeliser's 40-sample halo in front of a launch, two blocks by stream parity (nvx_kernels.h)
+        for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_whist[i], (size_t)h->n_in * 40 * 4));
     if (cfg->push_mode) {
         h->stage_cap = (size_t)(cfg->max_frames + 1) * h->frame_in;
         for (int i = 0; i < 2; i++) {
@@ -227,6 +213,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->writing.assign(h->n_in, 0);
         h->pushing.assign(h->n_in, 0);
         h->last_push_ns.assign(h->n_in, nvx_now_ns());
+        h->stall_ns.assign(h->n_in, cfg->stall_timeout_ms < 0 ? 0 : (int64_t)(cfg->stall_timeout_ms ? cfg->stall_timeout_ms : 2000) * 1000000);
     }
 #undef CR_TRY
     rc = nvx_reset(h);
@@ -256,13 +243,9 @@ extern "C" int nvx_reset(nvx_handle *h)
     for (ArrivalClock *ac : h->arrival)
         if (ac) { std::lock_guard<std::mutex> al(ac->mu); ac->base = UINT64_MAX; }
     h->demod_pending[0] = h->demod_pending[1] = false;
-    h->fsm_pending = false;
-    if (h->stream3) {
-        HIP_TRY(hipStreamSynchronize(h->stream3));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_whist[i], 0, (size_t)h->n_in * 40 * 4, h->stream));
-        h->sub_busy[0] = h->sub_busy[1] = false;
-        h->wide_launches = 0;
-    }
+    h->poisoned = false; h->poison_why.clear();
+    std::fill(h->ended.begin(), h->ended.end(), (uint8_t)0);
+    for (int i = 0; i < 2 && h->d_whist[i]; i++) HIP_TRY(hipMemsetAsync(h->d_whist[i], 0, (size_t)h->n_in * 40 * 4, h->stream));
     for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(h->d_cstate[i], 0, (size_t)h->n_streams * NVX_CASCADE_STATE_BYTES, h->stream));
     // FIR3's history: silence in front of every chain's first launch (the prefix of every y2 row, both buffers)
     for (int i = 0; i < 2 && h->d_y2[i]; i++)
@@ -290,21 +273,27 @@ extern "C" int nvx_reset(nvx_handle *h)
     return NVX_OK;
 }
 
-bool nvx_wb_fused()
-{
-    static const bool fused = !(getenv("NVX_WB_FUSED") && atoi(getenv("NVX_WB_FUSED")) == 0);
-    return fused;
-}
-
 // launch cascade + demod over n_frames frames of [n_streams][pitch] packed IQ
+// tail_n3 (end of a stream's input, nvx_finish): per participant, how many of the launch's 900 S/s samples the stream's
+// REAL input produces -- the demodulator stops there (the reference's loop consumes exactly the samples it is given and
+// stops: receiver/capt_sched.c:509-513); such a stream is ended afterwards.
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
-                      bool input_on_stream3, const int *part, int n_part)
+                      const int *part, int n_part, const int *tail_n3)
 {
+    if (h->poisoned) return nvx_poisoned_error(h);
     if (n_frames < 1 || n_frames > h->cfg.max_frames) { nvx_set_error("n_frames %d outside 1..max_frames %d", n_frames, h->cfg.max_frames); return NVX_ERR_ARG; }
     if ((pitch & 3) || (first_sample & 3)) { nvx_set_error("pitch and first sample must be multiples of 4 samples"); return NVX_ERR_ARG; }
     if (part && (n_part < 1 || n_part > h->n_in)) { nvx_set_error("launch with %d of %d streams", n_part, h->n_in); return NVX_ERR_ARG; }
-    if (part && n_part == h->n_in) part = nullptr;      // ascending and distinct: that is every stream
-    if (part && h->cfg.wideband && !nvx_wb_fused()) { nvx_set_error("the two-kernel wideband form (NVX_WB_FUSED=0) launches all streams together"); return NVX_ERR_STATE; }
+    if (part && n_part == h->n_in && !tail_n3) part = nullptr;      // ascending and distinct: that is every stream
+    // (validated before anything is enqueued or committed; `diverged` and the statistics move only behind the last enqueue)
+    for (int i = 0; part && i < n_part; i++)
+        if (part[i] < 0 || part[i] >= h->n_in || (i > 0 && part[i] <= part[i - 1])) { nvx_set_error("launch list: stream %d out of order or range", part[i]); return NVX_ERR_ARG; }
+    const int n_named = part ? n_part : h->n_in;
+    for (int i = 0; i < n_named; i++) {
+        const int s = part ? part[i] : i;
+        if (h->ended[s]) { nvx_set_error("stream %d has ended (nvx_finish): nvx_reset starts a new one", s); return NVX_ERR_STATE; }
+        if (tail_n3 && (tail_n3[i] < 1 || tail_n3[i] >= n_frames * NVX_FRAME_Y3)) { nvx_set_error("launch list: %d samples at 900 S/s in the tail of stream %d", tail_n3[i], s); return NVX_ERR_ARG; }
+    }
     Result &r = h->res[h->launched % RESULT_SLOTS];
     // Ring full: take in the OLDEST result only (launched RESULT_SLOTS launches ago, long finished), so that the launches
     // behind it keep the GPU busy while the host appends its bits.  (Collecting everything here drained the pipeline every
@@ -317,89 +306,40 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     // a launch on another stream than its predecessor: order it behind the predecessor's last operation
     if (h->launch_done_valid && st != h->last_launch_stream) HIP_TRY(hipStreamWaitEvent(st, h->launch_done, 0));
 
-    const int wb = (int)(h->wide_launches & 1);
-    // Measured (profiles/r01, DESIGN.md tuning log): letting the channeliser of launch k+1 run beside the
-    // cascade of launch k (own stream, cascade grid capped at 8 waves per CU to leave LDS) LOSES: 22.2 vs
-    // 21.2 ms per step -- the capped cascade and the demodulator slow down by more than the 6 ms hidden.
-    // Default: channeliser in front of the cascade on the same stream.  NVX_WB_OVERLAP=1 re-enables it.
-    static const bool wb_overlap = getenv("NVX_WB_OVERLAP") && atoi(getenv("NVX_WB_OVERLAP")) == 1;
-    // Wideband handles run the fused kernel (nvx_wideband_fused.hip: the stream is read once, the sub-bands never
-    // leave the LDS).  NVX_WB_FUSED=0 selects the two-kernel form (channeliser -> sub-band buffer -> cascade): A/B runs.
-    const bool fused = h->cfg.wideband && nvx_wb_fused();
-    const void *d_wide = d_iq; const size_t wide_pitch = pitch, wide_first = first_sample;
-    if (h->cfg.wideband && !fused) {
-        // channeliser into sub[wb]; sub[wb] was last read by the cascade two launches ago
-        hipStream_t s3 = (wb_overlap || input_on_stream3) ? h->stream3 : st;
-        // Input ordering.  Push path: the H2D copy was issued on stream3 itself.  Resident path on the
-        // handle's own stream: the caller made the data ready before the call (an event recorded on that
-        // stream would also capture the previous cascade and serialise the overlap away).  A caller-supplied
-        // stream may have produced the input, so the channeliser waits for it.
-        if (!input_on_stream3 && st != h->stream) {
-            HIP_TRY(hipEventRecord(h->in_ready[wb], st));
-            HIP_TRY(hipStreamWaitEvent(s3, h->in_ready[wb], 0));
-        }
-        if (h->sub_busy[wb]) HIP_TRY(hipStreamWaitEvent(s3, h->sub_free[wb], 0));
-        int rc = nvx_channelise_resident(h->cfg.device, d_iq, pitch, first_sample, h->n_in, (size_t)n_frames * NVX_FRAME_IN,
-                                         h->d_whist[wb], h->d_whist[wb ^ 1], h->d_sub[wb], (size_t)h->cfg.max_frames * NVX_FRAME_IN, 0, s3);
-        if (rc != NVX_OK) return rc;
-        HIP_TRY(hipEventRecord(h->chan_done[wb], s3));
-        HIP_TRY(hipStreamWaitEvent(st, h->chan_done[wb], 0));
-        d_iq = h->d_sub[wb];
-        pitch = (size_t)h->cfg.max_frames * NVX_FRAME_IN;
-        first_sample = 0;
-    }
-
+    const bool fused = h->cfg.wideband != 0;           // wideband handles run nvx_wideband_fused + nvx_fir3 (nvx_wideband_fused.hip)
     const int yb = (int)(h->launched & 1);              // y3 buffer of this launch
-    // Where the demodulator runs (measured, DESIGN.md tuning log).  Its time-parallel front needs LDS, and the
-    // persistent cascade grid owns every CU's LDS: beside the NEXT cascade launch it only becomes resident as
-    // that drains (loses), so it stays on the cascade's stream.  The sequential FSM kernel is 64 waves without
-    // LDS and does run beside the next cascade (NVX_FSM_OVERLAP=1, second stream), but what it hides (0.34 ms)
-    // the cascade loses again (20.1 vs 19.8 ms): step time equal, so the default is one stream.
-    static const bool fsm_overlap = getenv("NVX_FSM_OVERLAP") && atoi(getenv("NVX_FSM_OVERLAP")) == 1;
-    // The whole demodulator of launch k runs on the second stream, beside the cascade of launch k + 1, whose persistent
-    // grid is one wave per CU short of what fits so that a workgroup of the front (14 KB of LDS) finds room on every CU:
-    // step 20.9 -> 20.5 ms on the headline workload (DESIGN.md tuning log).  NVX_DEMOD_OVERLAP=0 puts it back on the
-    // cascade's stream, =n (n > 1) caps the grid at n waves per CU instead (A/B runs).
-    static const int demod_overlap = getenv("NVX_DEMOD_OVERLAP") ? atoi(getenv("NVX_DEMOD_OVERLAP")) : 1;
-    hipStream_t s2 = (fsm_overlap || demod_overlap > 0) ? h->stream2 : st;
-    hipStream_t sd = demod_overlap > 0 ? h->stream2 : st;
+    // Where the demodulator runs (measured, profiles/TUNING.md): the whole demodulator of launch k -- nvx_fir3 of a
+    // wideband handle, front, FSM, bit download -- runs on the second stream, beside the cascade of launch k + 1, whose
+    // persistent grid is one wave per CU short of what fits so that a workgroup of the front (14 KB of LDS) finds room on
+    // every CU: step 20.9 -> 20.5 ms on the headline workload.
+    hipStream_t sd = h->stream2;
     // Who takes part.  While every launch has covered every stream, all streams share one state-block parity and one
     // sample count and the kernels need no list.  From the first partial launch on (a stream of a push-mode handle had
     // no frame) the streams are on their own clocks: the launch carries a list with each participant's parity and g0.
+    // A launch that ends streams carries one too (their true sample counts).
     const int per_part = h->cfg.wideband ? NVX_WB_SUBBANDS : 1;          // decoded streams per input stream
-    // (validated before anything is enqueued or committed; `diverged` and the statistics move only behind the last enqueue)
-    for (int i = 0; part && i < n_part; i++)
-        if (part[i] < 0 || part[i] >= h->n_in || (i > 0 && part[i] <= part[i - 1])) { nvx_set_error("launch list: stream %d out of order or range", part[i]); return NVX_ERR_ARG; }
-    const bool with_list = h->diverged || part != nullptr;
+    const int n3_full = n_frames * NVX_FRAME_Y3;
+    const bool with_list = h->diverged || part != nullptr || tail_n3 != nullptr;
     r.n_part = 0;
     const nvx_part *d_list = nullptr;
     if (with_list) {
-        r.n_part = part ? n_part : h->n_in;
+        r.n_part = n_named;
         for (int i = 0; i < r.n_part; i++) {
             const int s = part ? part[i] : i;
-            r.h_part[i] = nvx_part{ s, (int)h->parity[s], h->g0s[s] };
+            r.h_part[i] = nvx_part{ s, (int)h->parity[s], h->g0s[s], tail_n3 ? tail_n3[i] : n3_full, 0 };
         }
         // (the slot's previous launch has been collected above, so neither copy of its list is still in use)
         HIP_TRY(hipMemcpyAsync(r.d_part, r.h_part, (size_t)r.n_part * sizeof(nvx_part), hipMemcpyHostToDevice, st));
         d_list = r.d_part;
     }
     const int n_here = with_list ? r.n_part : h->n_in;                   // input streams in this launch
-    nvx_cascade_args ca{};
-    ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
-    ca.n_frames = n_frames; ca.n_streams = h->cfg.wideband ? h->n_streams : n_here; ca.chain_masks = h->d_masks;
-    ca.part = h->cfg.wideband ? nullptr : d_list;
     // without a list every stream has the same parity: the kernels then read state[0] and write state[1]
     const int p0 = d_list ? 0 : (int)h->parity[0];
-    ca.state[0] = h->d_cstate[p0]; ca.state[1] = h->d_cstate[p0 ^ 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
-    ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
-    // wideband: leave LDS room beside the persistent cascade grid for the next launch's channeliser workgroups
-    ca.stage0_order = h->cfg.stage0_order;
-    ca.third0 = (unsigned)(h->g0s[0] / (NVX_FRAME_Y3 / 3));        // the state blocks' tag (nvx_kernels.h): position in thirds of a frame
+    const unsigned third0 = (unsigned)(h->g0s[0] / (NVX_FRAME_Y3 / 3));  // the state blocks' tag (nvx_kernels.h): position in thirds of a frame
     // FIR2 output buffers (fused wideband kernel): with a list [parity of the stream]; without one the buffer to write as [0]
     double2 *const y2_bufs[2] = { h->d_y2[d_list ? 0 : p0], h->d_y2[d_list ? 1 : p0 ^ 1] };
-    ca.max_waves_per_cu = (h->cfg.wideband && wb_overlap) ? 8 : (demod_overlap > 1 ? demod_overlap : (demod_overlap == 1 ? -1 : 0));
     nvx_demod_args da{};
-    da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n_frames * NVX_FRAME_Y3;
+    da.y3 = h->d_y3[yb]; da.y3_cap = (size_t)h->y3_cap; da.y3_base = 0; da.n3 = n3_full;
     da.n_slots = h->n_slots; da.slot_active = h->d_active;
     da.g0 = h->g0s[0]; da.part = d_list; da.n_part = r.n_part; da.per_part = per_part;
     da.dstate[0] = h->d_dd[p0]; da.dstate[1] = h->d_dd[p0 ^ 1];     // (read, write) without a list; [0], [1] with one
@@ -412,26 +352,33 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[0], st));
     if (fused) {
         nvx_wideband_args wa{};
-        wa.raw = (const uint32_t *)d_wide; wa.pitch = wide_pitch; wa.first_sample = wide_first;
+        wa.raw = (const uint32_t *)d_iq; wa.pitch = pitch; wa.first_sample = first_sample;
         wa.n_wide = n_here; wa.n_frames = n_frames; wa.chain_masks = h->d_masks;
         wa.part = d_list;
-        wa.state[0] = ca.state[0]; wa.state[1] = ca.state[1];
+        wa.state[0] = h->d_cstate[p0]; wa.state[1] = h->d_cstate[p0 ^ 1];
         wa.hist[0] = h->d_whist[p0]; wa.hist[1] = h->d_whist[p0 ^ 1];       // a stream reads [its parity], writes the other
-        wa.y3 = ca.y3; wa.y3_cap = ca.y3_cap; wa.y3_base = 0;
-        wa.queue = ca.queue; wa.status = ca.status; wa.done = ca.done; wa.third0 = ca.third0;
+        wa.y3 = h->d_y3[yb]; wa.y3_cap = (size_t)h->y3_cap; wa.y3_base = 0;
+        wa.queue = h->d_ctrl; wa.status = h->d_ctrl + 1; wa.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS; wa.third0 = third0;
         wa.y2[0] = y2_bufs[0]; wa.y2[1] = y2_bufs[1]; wa.y2_pitch = h->y2_pitch; wa.y2_row = h->d_y2row;
         HIP_TRY(nvx_launch_wideband_fused(&wa, st));
-        h->wide_launches++;
     } else {
+        nvx_cascade_args ca{};
+        ca.iq = (const uint32_t *)d_iq; ca.pitch = pitch; ca.first_sample = first_sample;
+        ca.n_frames = n_frames; ca.n_streams = n_here; ca.chain_masks = h->d_masks;
+        ca.part = d_list;
+        ca.state[0] = h->d_cstate[p0]; ca.state[1] = h->d_cstate[p0 ^ 1]; ca.y3 = h->d_y3[yb]; ca.y3_cap = (size_t)h->y3_cap; ca.y3_base = 0;
+        ca.queue = h->d_ctrl; ca.status = h->d_ctrl + 1; ca.done = h->d_ctrl + NVX_CASCADE_CTRL_INTS;
+        ca.stage0_order = h->cfg.stage0_order;
+        ca.third0 = third0;
+        ca.max_waves_per_cu = -1;                        // one fewer than fit: room for the previous launch's demodulator (above)
         HIP_TRY(nvx_launch_cascade(&ca, h->cascade_raw, h->nch, st));
     }
     if (r.timed) HIP_TRY(hipEventRecord(r.ev[1], st));
-    if (h->cfg.wideband && !fused) { HIP_TRY(hipEventRecord(h->sub_free[wb], st)); h->sub_busy[wb] = true; h->wide_launches++; }
     HIP_TRY(hipMemcpyAsync(h->h_status + NVX_STATUS_INTS * (h->launched % RESULT_SLOTS), h->d_ctrl + 1, NVX_STATUS_INTS * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(h->casc_done[yb], st));
-    // demodulator front behind the cascade; it reuses the word buffer the previous launch's FSM reads
-    if (sd != st) HIP_TRY(hipStreamWaitEvent(sd, h->casc_done[yb], 0));
-    else if (h->fsm_pending && s2 != st) HIP_TRY(hipStreamWaitEvent(st, h->fsm_done, 0));
+    // the demodulator behind the cascade, on its own stream (which also orders it behind the previous launch's FSM, whose
+    // word buffer the front reuses)
+    HIP_TRY(hipStreamWaitEvent(sd, h->casc_done[yb], 0));
     if (fused) {
         // FIR3 (the fused wideband kernel's waves end at FIR2): y2 rows -> y3[yb], in front of the demodulator on its stream
         nvx_fir3_args fa{};
@@ -448,26 +395,24 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     HIP_TRY(hipEventRecord(h->demod_done[yb], sd));      // y3[yb] consumed
     h->demod_pending[yb] = true;
     // FSM + bit download behind the front
-    if (s2 != sd) HIP_TRY(hipStreamWaitEvent(s2, h->demod_done[yb], 0));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[4], s2));
-    HIP_TRY(nvx_launch_demod_fsm(&da, s2));
-    if (r.timed) HIP_TRY(hipEventRecord(r.ev[5], s2));
-    HIP_TRY(hipEventRecord(h->fsm_done, s2));
-    h->fsm_pending = true;
-    HIP_TRY(hipMemcpyAsync(h->h_ties, h->d_ties, sizeof(nvx_tie_stats), hipMemcpyDeviceToHost, s2));
-    HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, s2));
-    HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, s2));
-    HIP_TRY(hipEventRecord(r.done, s2));
-    HIP_TRY(hipEventRecord(h->launch_done, s2));                    // s2 is st, or has waited for st's last operation
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[4], sd));
+    HIP_TRY(nvx_launch_demod_fsm(&da, sd));
+    if (r.timed) HIP_TRY(hipEventRecord(r.ev[5], sd));
+    HIP_TRY(hipMemcpyAsync(h->h_ties, h->d_ties, sizeof(nvx_tie_stats), hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(r.h_nbits, r.d_nbits, (size_t)h->n_slots * sizeof(int), hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipMemcpyAsync(r.h_bits, r.d_bits, (size_t)h->n_slots * h->bits_cap, hipMemcpyDeviceToHost, sd));
+    HIP_TRY(hipEventRecord(r.done, sd));
+    HIP_TRY(hipEventRecord(h->launch_done, sd));                    // sd has waited for st's last operation
     h->launch_done_valid = true; h->last_launch_stream = st;
     r.pending = true;
-    r.n3 = da.n3;
+    r.n3 = n3_full;
     r.g0_all = h->g0s[0];
     h->launched++;
-    h->last_n3 = da.n3;
+    h->last_n3 = n3_full;
     for (int i = 0; i < n_here; i++) {                   // the participants have moved on: other block, n3 more samples
         const int s = with_list ? r.h_part[i].stream : i;
-        h->parity[s] ^= 1; h->g0s[s] += (unsigned long long)da.n3;
+        h->parity[s] ^= 1; h->g0s[s] += (unsigned long long)(tail_n3 ? tail_n3[i] : n3_full);
+        if (tail_n3) h->ended[s] = 1;                    // its filters have run into whatever lay behind its last sample
     }
     if (part) h->partial_launches++;
     // from the first partial launch on the streams are on their own clocks (every launch carries a list) -- until they
@@ -497,6 +442,12 @@ int nvx_collect_ready_locked(nvx_handle *h)
     return NVX_OK;
 }
 
+int nvx_poisoned_error(nvx_handle *h)
+{
+    nvx_set_error("a launch of this handle failed (%s): nvx_reset it", h->poison_why.c_str());
+    return NVX_ERR_STATE;
+}
+
 int nvx_launches_in_flight(nvx_handle *h)
 {
     std::lock_guard<std::mutex> lk(h->mu);
@@ -513,6 +464,7 @@ extern "C" int nvx_poll(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);
     if (h->collected == h->launched) return NVX_OK;          // nothing in flight: no HIP call at all
     HIP_TRY(hipSetDevice(h->cfg.device));
     return nvx_collect_ready_locked(h);
@@ -530,14 +482,23 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
             h->wait_polls += (uint64_t)(unsigned)stat[1]; h->wait_units += (uint64_t)(unsigned)stat[2]; h->wait_launches++;
             h->stale_repaired += (uint64_t)(unsigned)stat[3];
             if (stat[0] != 0) {
-                // (the launch's bits are not taken in: whatever it produced rests on a state nobody vouches for)
+                // The launch's bits are not taken in: whatever it produced rests on a state nobody vouches for.  Nor can
+                // anything behind it be trusted: the unit that found the bad block ran on and sealed what it computed from
+                // it, the demodulator state moved on too, and the launches already queued inherit both under valid seals.
+                // So the failure sticks (nvx_handle.h, poisoned): every pending result is dropped here, and the handle
+                // answers NVX_ERR_STATE until nvx_reset.
                 if (stat[0] == NVX_STATUS_INTEGRITY) {
                     h->integrity_failures++;
-                    nvx_set_error("FIR cascade: the filter state a launch inherited from its predecessor failed its integrity word (nvx_reset the handle)");
+                    h->poison_why = "the filter state a launch inherited from its predecessor failed its integrity word";
                 } else {
-                    nvx_set_error("FIR cascade work queue: a wait on the previous frame of a stream timed out");
+                    h->poison_why = "a wait on the previous frame of a stream timed out in the FIR cascade's work queue";
                 }
-                r.pending = false; h->collected++;
+                h->poisoned = true;
+                // (launch_done covers every queued launch: nothing of them is in flight when their slots are released)
+                if (h->launch_done_valid) (void)hipEventSynchronize(h->launch_done);
+                for (auto &q : h->res) q.pending = false;
+                h->collected = h->launched;
+                nvx_set_error("FIR cascade: %s; the results of this launch and of the launches queued behind it are discarded (nvx_reset the handle)", h->poison_why.c_str());
                 return NVX_ERR_HIP;
             }
             if (r.timed) {
@@ -648,6 +609,7 @@ extern "C" int nvx_fetch_bits(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);
     HIP_TRY(hipSetDevice(h->cfg.device));
     return nvx_collect_locked(h);
 }

@@ -11,12 +11,11 @@ struct nvx_capture {
     std::vector<int16_t> ring;                  // interleaved I,Q (capt_sched.c:443: shorts)
     size_t cap = 0;                             // complex samples
     std::atomic<uint64_t> head{ 0 }, tail{ 0 }; // samples ever written / ever read
-    std::atomic<uint64_t> received{ 0 }, dropped{ 0 }, consumed{ 0 }, full_waits{ 0 };
+    std::atomic<uint64_t> received{ 0 }, dropped{ 0 }, consumed{ 0 };
     std::mutex prod_mu;                         // callback re-entrancy (capt_sched.c:111)
     std::mutex cv_mu; std::condition_variable cv;
     std::atomic<bool> stop{ false }, paused{ false };
     std::atomic<int> error{ NVX_OK };
-    int stalled = 0;                            // consumer only: consecutive back-pressure rounds in which nothing was taken
     // A radio that goes silent (unplugged: receiver/capt_sched.c:210-212 only prints sdrplay_api_DeviceRemoved) must not
     // hold the other streams of the handle: after stall_ms without a sample handed on, the consumer marks its stream
     // inactive (nvx_stream_set_active) -- launches stop waiting for it -- and says so (nvx_capture_stalled).  The next
@@ -59,19 +58,12 @@ static void capture_consumer(nvx_capture *c)
         }
         if (c->paused.load() && !c->stop.load()) continue;
         uint64_t t = c->tail.load(), hd = c->head.load();
-        bool backoff = false;
-        const uint64_t t_in = t;
         while (t != hd && !(c->paused.load() && !c->stop.load())) {      // contiguous spans, wrap split as capt_sched.c:494-503
             size_t at = (size_t)(t % c->cap);
             size_t n = (size_t)std::min<uint64_t>(hd - t, c->cap - at);
             size_t took = 0;
             int rc = nvx_push_iq_partial(c->h, c->stream, c->ring.data() + 2 * at, n, &took);
-            // NVX_ERR_FULL (only the two-kernel wideband form still produces it: its streams launch together and another
-            // one is a whole staging set behind): back-pressure, not an error.  Keep what was not taken in the ring (its
-            // overrun accounting counts any loss) and retry after the poll interval.  While stopping, a handle that
-            // takes nothing for a second is given up on (NVX_ERR_FULL).
-            if (rc == NVX_ERR_FULL) { c->full_waits.fetch_add(1); backoff = true; }
-            else if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }      // hard error (HIP): give up, report
+            if (rc != NVX_OK) { c->error.store(rc); c->stop.store(true); return; }      // a failed launch or HIP call: give up, report
             n = took;
             if (n) {
                 std::lock_guard<std::mutex> lk(c->rec_mu);
@@ -83,15 +75,7 @@ static void capture_consumer(nvx_capture *c)
             c->tail.store(t);
             c->consumed.fetch_add(n);
             if (n) { last_progress = std::chrono::steady_clock::now(); seen_any = true; c->silent.store(0); }     // (the push made the stream active again)
-            if (backoff) break;
         }
-        if (backoff) {
-            c->stalled = (c->tail.load() == t_in) ? c->stalled + 1 : 0;
-            if (c->stop.load() && c->stalled >= 20) { c->error.store(NVX_ERR_FULL); return; }
-            std::this_thread::sleep_for(std::chrono::milliseconds(50));
-            continue;
-        }
-        c->stalled = 0;
         if (c->stop.load() && c->head.load() == c->tail.load()) return;
     }
 }
@@ -114,6 +98,7 @@ extern "C" int nvx_capture_start(nvx_handle *h, int stream, double ring_seconds,
         c->clock.base = h->g0s[stream] / NVX_FRAME_Y3 + (h->fill.empty() ? 0 : h->fill[stream] / h->frame_in);
         if (!h->arrival[stream]) h->n_arrival++;
         h->arrival[stream] = &c->clock;
+        c->stall_ms.store((int)(h->stall_ns[stream] / 1000000));        // one timeout for the stream: the handle's, until nvx_capture_set_stall_timeout
     }
     c->worker = std::thread(capture_consumer, c);
     *out = c;
@@ -198,10 +183,9 @@ extern "C" void nvx_capture_stats(nvx_capture *c, uint64_t *received, uint64_t *
     if (consumed) *consumed = c->consumed.load();
 }
 
-extern "C" int nvx_capture_error(nvx_capture *c, uint64_t *full_waits)
+extern "C" int nvx_capture_error(nvx_capture *c)
 {
     if (!c) return NVX_ERR_ARG;
-    if (full_waits) *full_waits = c->full_waits.load();
     return c->error.load();
 }
 
@@ -214,7 +198,13 @@ extern "C" int nvx_capture_stalled(nvx_capture *c, uint64_t *stall_events)
 
 extern "C" void nvx_capture_set_stall_timeout(nvx_capture *c, double seconds)
 {
-    if (c) c->stall_ms.store(seconds > 0 ? (int)(seconds * 1000.0 + 0.5) : 0);
+    if (!c) return;
+    const int ms = seconds > 0 ? (int)(seconds * 1000.0 + 0.5) : 0;
+    c->stall_ms.store(ms);
+    // ... and the same figure at the push level (nvx_push.cpp, lockstep_ready), so that ONE timeout says how long the other
+    // streams' launches wait for this radio: the ring's (0 = for ever)
+    std::lock_guard<std::mutex> lk(c->h->mu);
+    c->h->stall_ns[c->stream] = (int64_t)ms * 1000000;
 }
 
 extern "C" int nvx_capture_stop(nvx_capture *c)

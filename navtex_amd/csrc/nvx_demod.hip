@@ -159,19 +159,22 @@ __device__ __forceinline__ unsigned short front_word(const unsigned char *d9, co
     return (unsigned short)(w | (max_index << 12));
 }
 
-// which chain a block works on, which of the two state blocks it reads (it writes the other) and the chain's sample count
-struct FrontChain { int slot; unsigned long long g0; const double *st_rd; double *st_wr; };
+// which chain a block works on, which of the two state blocks it reads (it writes the other), the chain's sample count
+// and how many samples at 900 S/s this launch holds for it -- whole frames, except in the launch that ENDS the chain's
+// stream (nvx_finish: nvx_part.n3), where the count is what the stream's real input produced and the last bit period may
+// be ragged: the reference's decoder simply stops with its last sample (receiver/capt_sched.c:509-513)
+struct FrontChain { int slot; unsigned long long g0; const double *st_rd; double *st_wr; int n3; };
 __device__ __forceinline__ FrontChain front_chain(const nvx_demod_args &a, int chain_index)
 {
     // every slot, or the slots of the launch's participants (nvx_kernels.h, nvx_part: entry e covers the decoded streams
     // per_part * stream .. + per_part - 1, two slots each, and carries their common sample count and parity)
     FrontChain c;
-    c.slot = chain_index; c.g0 = a.g0;
+    c.slot = chain_index; c.g0 = a.g0; c.n3 = a.n3;
     int parity = 0;
     if (a.part) {
         const int per = 2 * a.per_part, e = chain_index / per;
         c.slot = a.part[e].stream * per + (chain_index - e * per);
-        c.g0 = a.part[e].g0; parity = a.part[e].parity;
+        c.g0 = a.part[e].g0; parity = a.part[e].parity; c.n3 = a.part[e].n3;
     }
     c.st_rd = (parity ? a.dstate[1] : a.dstate[0]) + (size_t)c.slot * NVX_DEMOD_DOUBLES;
     c.st_wr = (parity ? a.dstate[0] : a.dstate[1]) + (size_t)c.slot * NVX_DEMOD_DOUBLES;
@@ -219,9 +222,11 @@ __device__ __forceinline__ void front_sequential(const nvx_demod_args &a, int ch
     for (int i = tid; i < 567; i += NVX_FRONT_THREADS) s_C[i] = st[DS_C + i];
     __syncthreads();
 
-    const int n_here = n_tiles_here > 0 ? min(a.n3, n_tiles_here * DTL) : a.n3;
+    const int n3 = ch.n3;
+    const int n_here = n_tiles_here > 0 ? min(n3, n_tiles_here * DTL) : n3;
     for (int ta = 0; ta < n_here; ta += DTL) {
         const int tl = min(DTL, n_here - ta);
+        const int tl9 = (tl + 8) / 9;                    // bit periods of the tile, the last one perhaps ragged (end of the stream)
         const unsigned long long gt = ch.g0 + (unsigned long long)ta;    // g of L = 0
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS) {
             const int t = ta + L;
@@ -231,6 +236,7 @@ __device__ __forceinline__ void front_sequential(const nvx_demod_args &a, int ch
             if (dphi_out) dphi_out[t] = ds;
             s_D[L] = front_decision(y3_at(y3, hist, t - 4), y3_at(y3, hist, t - 3), y3_at(y3, hist, t - 2), w3, w4);
         }
+        if (tid < 9 * tl9 - tl) s_D[tl + tid] = 0;       // a ragged last period: no window ends on samples the stream never had
         __syncthreads();
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS)
             s_C[567 + L] = (gt + L >= G_DAB) ? front_corr(&s_dphi[L]) : 0.0;      // (0: never read; keeps the carried state deterministic)
@@ -240,9 +246,9 @@ __device__ __forceinline__ void front_sequential(const nvx_demod_args &a, int ch
         for (int L = tid; L < tl; L += NVX_FRONT_THREADS)
             s_S[8 + L] = (gt + L >= G_CB) ? front_class_sum(&s_C[567 + L], t_cb + (unsigned)L) : 0.0;
         __syncthreads();
-        for (int M = tid; M < tl / 9; M += NVX_FRONT_THREADS) {
-            const int L = 9 * M + (G_CSA % 9);
-            a.words[(size_t)slot * (a.y3_cap / 9) + (ta / 9 + M)] = front_word(&s_D[9 * M], &s_S[L], gt + L >= G_CSA, ties);
+        for (int M = tid; M < tl9; M += NVX_FRONT_THREADS) {
+            const int L = 9 * M + (G_CSA % 9);             // (L >= tl: the stream ended before this period's timing evaluation)
+            a.words[(size_t)slot * (a.y3_cap / 9) + (ta / 9 + M)] = front_word(&s_D[9 * M], &s_S[L], L < tl && gt + L >= G_CSA, ties);
         }
         __syncthreads();
         // ---- slide the histories to the front for the next tile / the next launch
@@ -260,7 +266,7 @@ __device__ __forceinline__ void front_sequential(const nvx_demod_args &a, int ch
     front_publish_ties(a, ties, &s_near, &s_evals, &s_minm, tid);
     if (n_tiles_here > 0) return;                        // the last tile of the tile-parallel form stores the state
     double *sw = ch.st_wr;
-    if (tid < 4 && a.n3 >= 4) { const double2 l = y3[a.n3 - 4 + tid]; sw[DS_Y3 + 2 * tid] = l.x; sw[DS_Y3 + 2 * tid + 1] = l.y; }
+    if (tid < 4 && n3 >= 4) { const double2 l = y3[n3 - 4 + tid]; sw[DS_Y3 + 2 * tid] = l.x; sw[DS_Y3 + 2 * tid + 1] = l.y; }
     if (tid < 8) { sw[DS_DPHI + tid] = s_dphi[tid]; sw[DS_S + tid] = s_S[tid]; }
     for (int i = tid; i < 567; i += NVX_FRONT_THREADS) sw[DS_C + i] = s_C[i];
 }
@@ -356,10 +362,12 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     __syncthreads();
     int slot = blockIdx.x * 64 + threadIdx.x;
     const int nc = a.n_slots;
+    int n3 = a.n3;
     if (a.part) {                                        // the slots of the launch's participants, as in the front kernel
         const int per = 2 * a.per_part, e = slot / per;
         if (e >= a.n_part) return;
         slot = a.part[e].stream * per + (slot - e * per);
+        n3 = a.part[e].n3;
     }
     if (slot >= nc) return;
     if (!a.slot_active[slot]) return;
@@ -378,14 +386,16 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
     const int cap_words = a.bits_cap / 4;
     unsigned long long acc = 0;                   // pending bits, LSB first
     int nacc = 0, nwords = 0;                     // bits pending in acc (< 64), words already stored
-    const int periods = a.n3 / 9;                 // launches are whole frames: n3 = 288 * frames
+    const int periods = n3 / 9;                   // whole frames (288 * frames), except in the launch that ends the stream
     // one row of 16-bit words per chain: eight bit periods per 16-byte load, requested one group ahead
-    const uint4 *words = (const uint4 *)(a.words + (size_t)slot * (a.y3_cap / 9));
+    const unsigned short *wrow = a.words + (size_t)slot * (a.y3_cap / 9);
+    const uint4 *words = (const uint4 *)wrow;
     uint4 wnext = words[0];
 
-    for (int m0 = 0; m0 < periods; m0 += 8) {     // periods is a multiple of 32
+    int m0 = 0;
+    for (; m0 + 8 <= periods; m0 += 8) {
         const uint4 wv = wnext;
-        if (m0 + 8 < periods) wnext = words[m0 / 8 + 1];
+        if (m0 + 16 <= periods) wnext = words[m0 / 8 + 1];
         const unsigned wcur[8] = { wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16,
                                    wv.z & 0xffffu, wv.z >> 16, wv.w & 0xffffu, wv.w >> 16 };
 #pragma unroll
@@ -400,6 +410,23 @@ __global__ __launch_bounds__(64) void nvx_demod_fsm(nvx_demod_args a)
             if (nwords < cap_words) bits[nwords] = (unsigned)acc;
             nwords++; acc >>= 32; nacc -= 32;
         }
+    }
+    // the end of a stream (nvx_finish): the whole periods that do not fill a group of eight, then the samples of the ragged
+    // last period one at a time, by the per-sample rule the table is generated from (nvx_fsm.h; decoder.C:62-137, 202-249)
+    for (; m0 < periods; m0++) {
+        int n;
+        const unsigned b = nvx_fsm_period(s_tab, wrow[m0], &r, &n);
+        acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
+        nacc += n;
+        if (nacc >= 32) { if (nwords < cap_words) bits[nwords] = (unsigned)acc; nwords++; acc >>= 32; nacc -= 32; }
+    }
+    if (const int rem = n3 - 9 * periods) {
+        const unsigned w = wrow[periods];
+        int n;
+        const unsigned b = nvx_fsm_partial_period(w, rem, &r, &n);
+        acc |= (unsigned long long)(b & ((1u << n) - 1u)) << nacc;
+        nacc += n;
+        if (nacc >= 32) { if (nwords < cap_words) bits[nwords] = (unsigned)acc; nwords++; acc >>= 32; nacc -= 32; }
     }
     if (nacc > 0 && nwords < cap_words) bits[nwords] = (unsigned)acc;
 
@@ -422,6 +449,7 @@ extern "C" hipError_t nvx_launch_demod_front(const nvx_demod_args *a, hipStream_
     static const int force = getenv("NVX_DEMOD_TILES") ? atoi(getenv("NVX_DEMOD_TILES")) : -1;
     const int tiles = (a->n3 + DTL - 1) / DTL;
     const long long chain_frames = (long long)chains * (a->n3 / NVX_Y3_PER_FRAME);
+    // (the tile form works on a.n3: every chain whole frames.  A launch that ends streams is one frame long: the walk.)
     const bool parallel = tiles >= 3 && (force >= 0 ? force != 0 : chain_frames <= 2560);
     if (parallel) {
         const int wgs = tiles - 2;                           // one workgroup per tile from the third on; the head walks the first two

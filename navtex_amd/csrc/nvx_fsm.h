@@ -132,4 +132,29 @@ NVX_FSM_HD unsigned nvx_fsm_period(const uint32_t *tab, unsigned w, nvx_fsm_regs
     return ((w >> NVX_FSM_E_K1(e)) & 1u) | (((w >> NVX_FSM_E_K2(e)) & 1u) << 1);
 }
 
+/* The first `rem` (1..8) samples of a bit period -- the period in which a stream's input ends: the per-sample rule
+ * itself, sample by sample (the reference's decoder stops with its last sample, receiver/capt_sched.c:509-513).  w as
+ * above; its timing arg-max is only looked at when the period's sample 6 exists.  Returns the decided bits, *n_out of them. */
+NVX_FSM_HD unsigned nvx_fsm_partial_period(unsigned w, int rem, nvx_fsm_regs *r, int *n_out)
+{
+    int synced = r->so != NVX_FSM_UNSYNCED;
+    int phase = r->phase1 - 1, sync_off = synced ? r->so : 0, next_sync_off = r->nso, prev_offset = r->prev_offset;
+    unsigned bits = 0;
+    int n = 0;
+    for (int k = 0; k < rem; k++) {
+        if (k == NVX_FSM_TIMING_SAMPLE) {
+            int offset = 0;
+            if (nvx_fsm_timing((int)(w >> 12), &prev_offset, &offset)) {          /* decoder.C:62-70: bd_in_bit_sync */
+                sync_off = synced ? sync_off : offset;
+                next_sync_off = offset;
+                synced = 1;
+            }
+        }
+        if (nvx_fsm_bit_step(k, synced, &phase, &sync_off, next_sync_off)) { bits |= ((w >> k) & 1u) << n; n++; }
+    }
+    r->phase1 = phase + 1; r->so = synced ? sync_off : NVX_FSM_UNSYNCED; r->nso = next_sync_off; r->prev_offset = prev_offset;
+    *n_out = n;
+    return bits;
+}
+
 #endif

@@ -47,8 +47,14 @@ extern "C" int nvx_fsm_selftest(uint32_t seed, int periods)
             }
             if (nvx_fsm_bit_step(k, synced, &phase, &sync_off, next_sync_off)) { want |= ((w >> k) & 1u) << n_want; n_want++; }
         }
+        // the sample-by-sample form the kernel uses in the period in which a stream ENDS, carried through all nine samples:
+        // the same bits and registers as the table
+        nvx_fsm_regs rp = r;
+        int n_part;
+        const unsigned part = nvx_fsm_partial_period(w, 9, &rp, &n_part);
         int n_got;
         const unsigned got = nvx_fsm_period(tab, w, &r, &n_got) & ((1u << n_got) - 1u);
+        if (n_part != n_got || part != got || rp.phase1 != r.phase1 || rp.so != r.so || rp.nso != r.nso || rp.prev_offset != r.prev_offset) bad++;
         if (n_got != n_want || got != want) bad++;
         if (r.phase1 != phase + 1 || r.nso != next_sync_off || r.prev_offset != prev_a ||
             (r.so != NVX_FSM_UNSYNCED) != (synced != 0) || (synced && r.so != sync_off)) bad++;

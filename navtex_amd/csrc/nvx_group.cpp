@@ -236,6 +236,14 @@ extern "C" int nvx_group_flush(nvx_group *g)
     return group_join(g);
 }
 
+extern "C" int nvx_group_finish(nvx_group *g)
+{
+    if (!g) return NVX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g->api_mu);
+    for (Member *m : g->members) member_post(m, [m] { return nvx_finish(m->h); });
+    return group_join(g);
+}
+
 // decoded streams: in wideband mode global decoded stream 8 * w + k belongs to input stream w
 extern "C" size_t nvx_group_poll_bits(nvx_group *g, int s, int chain, char *out, size_t cap)
 {

@@ -108,19 +108,12 @@ struct nvx_handle {
     size_t bit_history = NVX_BIT_HISTORY;
     bool cascade_raw = false;          // the cascade kernel's RAW switch (never set in wideband mode)
     size_t frame_in = 0;               // complex input samples per frame at the input rate
-    // wideband mode: channeliser on stream3 into sub[b], overlapping the cascade of the previous launch
-    hipStream_t stream3 = nullptr;
-    uint32_t *d_sub[2] = { nullptr, nullptr };
-    uint32_t *d_whist[2] = { nullptr, nullptr };
-    hipEvent_t chan_done[2] = { nullptr, nullptr }, sub_free[2] = { nullptr, nullptr }, in_ready[2] = { nullptr, nullptr };
-    bool sub_busy[2] = { false, false };
-    uint64_t wide_launches = 0;
+    uint32_t *d_whist[2] = { nullptr, nullptr };   // wideband handles: the channeliser's 40-sample halo in front of a launch, by stream parity
     int y3_cap = 0, bits_cap = 0;
     hipStream_t stream = nullptr;      // FIR cascade (or the caller's stream) and H2D staging
-    hipStream_t stream2 = nullptr;     // demodulator FSM + D2H of the bits: overlaps the next cascade launch
+    hipStream_t stream2 = nullptr;     // the demodulator (nvx_fir3 of a wideband handle, front, FSM) + D2H of the bits: beside the next cascade launch
     hipEvent_t casc_done[2] = { nullptr, nullptr };   // y3[b] written
     hipEvent_t demod_done[2] = { nullptr, nullptr };  // y3[b] consumed
-    hipEvent_t fsm_done = nullptr; bool fsm_pending = false;   // word buffer consumed
     // Everything a launch carries (work queue, cascade state, demodulator state, word buffer) is ordered by stream
     // order on the launch stream.  launch_done is recorded behind the last operation of every launch; a launch on a
     // DIFFERENT stream than its predecessor waits for it, and reset / enable_debug / destroy wait for it on the host,
@@ -132,8 +125,8 @@ struct nvx_handle {
     uint8_t *d_masks = nullptr, *d_active = nullptr;
     uint8_t *d_cstate[2] = { nullptr, nullptr };   // cascade state blocks: launch k reads [k & 1], writes [(k + 1) & 1]
     double2 *d_y3[2] = { nullptr, nullptr };   // double buffer between the two streams
-    // 252 kS/s and wideband handles (the cascade kernels end at FIR2, nvx_kernels.h): FIR2 output rows, one per active
-    // chain, two buffers by stream parity; the row table; the HIP-event time of nvx_fir3
+    // wideband handles only (the fused wideband kernel's waves end at FIR2, nvx_kernels.h): FIR2 output rows, one per
+    // active chain, two buffers by stream parity; the row table
     double2 *d_y2[2] = { nullptr, nullptr };
     int *d_y2row = nullptr;
     size_t y2_pitch = 0; int y2_rows = 0;
@@ -154,6 +147,15 @@ struct nvx_handle {
     std::vector<unsigned long long> g0s;
     bool diverged = false;
     uint64_t partial_launches = 0;     // launches that covered only some of the streams, since create
+    // ended[s]: the stream's input has ended (nvx_finish ran its last, partial frame at its true length): its carried state
+    // is no continuation of anything -- pushes and launches are refused until nvx_reset
+    std::vector<uint8_t> ended;
+    // A launch failed (the state it inherited broke its seal, or a hand-over timed out): what the device carries from
+    // there on -- filter and demodulator state computed from the bad block, under fresh valid seals -- is garbage that
+    // every later launch would pass on.  Sticky: results of the launches queued behind it are dropped, launches, pushes,
+    // polls and fetches return NVX_ERR_STATE, nvx_reset clears it.
+    bool poisoned = false;
+    std::string poison_why;
     Result res[RESULT_SLOTS];
     std::vector<ArrivalClock *> arrival;   // per input stream: the capture ring's clock, or nullptr (guarded by mu)
     int n_arrival = 0;
@@ -191,6 +193,8 @@ struct nvx_handle {
     std::vector<uint8_t> writing;
     std::vector<uint8_t> pushing;              // stream s has a push call in progress (one pusher per stream, for the whole call)
     std::vector<int64_t> last_push_ns;         // when stream s last delivered samples (nvx_now_ns; create / reset count as a delivery)
+    std::vector<int64_t> stall_ns;             // how long the others' launches wait for stream s after that (0 = for ever): cfg.stall_timeout_ms,
+                                               // or the timeout of the capture ring attached to the stream (nvx_capture_set_stall_timeout)
     int writers = 0, quiesce = 0;
     std::condition_variable wr_cv;
 };
@@ -211,17 +215,18 @@ struct StagingQuiesce {
 
 // launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)
 // part / n_part: the input streams that take part, ascending (nullptr = every stream)
+// tail_n3 (per participant): the launch ends these streams -- so many of its 900 S/s samples are real (nvx_api.cpp)
 int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t first_sample, int n_frames, hipStream_t st,
-                      bool input_on_stream3 = false, const int *part = nullptr, int n_part = 0);
-// nvx_push_iq that reports how many samples it staged before NVX_ERR_FULL (or another error) stopped it
+                      const int *part = nullptr, int n_part = 0, const int *tail_n3 = nullptr);
+// nvx_push_iq that reports how many samples it staged before an error stopped it
 int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted);
-// wideband handles: the fused kernel (default) or channeliser + cascade (NVX_WB_FUSED=0)
-bool nvx_wb_fused();
 // wait for the launched blocks in front of launch number `upto` (default: every one), append bits, run the character
 // layer (handle locked)
 int nvx_collect_locked(nvx_handle *h, uint64_t upto = UINT64_MAX);
 // ... the same for every launched block that has ALREADY finished: never waits (handle locked)
 int nvx_collect_ready_locked(nvx_handle *h);
+// sets the "nvx_reset required" error text of a poisoned handle and returns NVX_ERR_STATE (handle locked)
+int nvx_poisoned_error(nvx_handle *h);
 // launches whose results have not been taken in yet (takes the handle's lock)
 int nvx_launches_in_flight(nvx_handle *h);
 // launches sent on their way since create (takes the handle's lock)

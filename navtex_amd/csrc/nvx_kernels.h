@@ -84,6 +84,10 @@ typedef struct {
     int stream;                /* stream index (input stream: a wideband handle's 2.016 MS/s stream)             */
     int parity;                /* the stream reads state block [parity] and writes [parity ^ 1]                  */
     unsigned long long g0;     /* 900 S/s samples the stream has been through since reset (multiple of 288)      */
+    int n3;                    /* 900 S/s samples of this launch the stream's REAL input produces: frames * 288, or fewer */
+                               /* in the launch that ends the stream (nvx_finish: the demodulator stops there; the        */
+                               /* reference's loop stops with its last sample, receiver/capt_sched.c:509-513)              */
+    int reserved;
 } nvx_part;
 
 typedef struct {
@@ -137,7 +141,7 @@ typedef struct {
 typedef struct {
     const double2 *y3;
     size_t y3_cap, y3_base;
-    int n3;                    /* 900 S/s samples in this launch                       */
+    int n3;                    /* 900 S/s samples in this launch (whole frames); part != NULL: per entry, and the last period may be ragged */
     int n_slots;               /* all streams * 2                                      */
     const uint8_t *slot_active;
     unsigned long long g0;     /* 900 S/s samples processed since reset (multiple of 288); part != NULL: per entry */

@@ -12,9 +12,9 @@
 static int n_whole_frames(const nvx_handle *h, int s) { return (int)(h->fill[s] / h->frame_in); }
 
 // A stream fed directly through nvx_push_* has no capture ring to declare it silent: one that has delivered nothing for
-// this long is not waited for either (the same 2 s as the ring's default stall timeout), so that the healthy streams keep
-// launching frame by frame instead of only when their staging is full.  Its next push counts again at once.
-#define NVX_PUSH_STALL_NS 2000000000ll
+// its stall timeout (cfg.stall_timeout_ms, default 2 s; a capture ring attached to the stream hands its own timeout on:
+// nvx_capture_set_stall_timeout; 0 = wait for ever) is not waited for either, so that the healthy streams keep launching
+// frame by frame instead of only when their staging is full.  Its next push counts again at once.
 
 // every active stream has a whole frame (and there is at least one that is waited for and has one)
 static bool lockstep_ready(const nvx_handle *h)
@@ -28,13 +28,15 @@ static bool lockstep_ready(const nvx_handle *h)
     for (int s = 0; s < h->n_in; s++) {
         if (!h->active[s]) continue;
         if (h->fill[s] < h->frame_in) {
-            if (now - h->last_push_ns[s] > NVX_PUSH_STALL_NS) continue;       // gone quiet: not waited for
+            if (h->stall_ns[s] > 0 && now - h->last_push_ns[s] > h->stall_ns[s]) continue;       // gone quiet: not waited for
             return false;
         }
         any = true;
     }
     return any;
 }
+
+static int submit_part_locked(nvx_handle *h, const std::vector<int> &part, int frames, const int *tail_n3);
 
 // Launch the streams that have at least one whole frame staged, with as many frames as all of THEM have.
 static int submit_locked(nvx_handle *h)
@@ -48,8 +50,14 @@ static int submit_locked(nvx_handle *h)
         frames = std::min(frames, f);
     }
     if (part.empty()) return NVX_OK;
-    const bool on_stream3 = h->cfg.wideband && !nvx_wb_fused();
-    if (on_stream3 && (int)part.size() != h->n_in) return NVX_OK;      // the two-kernel wideband form launches all streams together
+    return submit_part_locked(h, part, frames, nullptr);
+}
+
+// One launch out of the staging sets: `frames` frames of the streams in `part` (ascending).  tail_n3: the launch ENDS
+// these streams (nvx_finish) -- each has less than a frame staged, the rest of the frame is zeroed, and tail_n3[i] of the
+// launch's 900 S/s samples are real (nvx_launch_locked).
+static int submit_part_locked(nvx_handle *h, const std::vector<int> &part, int frames, const int *tail_n3)
+{
     const size_t take = (size_t)frames * h->frame_in;
     const size_t dpitch = (size_t)h->cfg.max_frames * h->frame_in;
     // a participant flips to its other staging set: that set must have left the copy engine (it was read by the copy
@@ -62,9 +70,10 @@ static int submit_locked(nvx_handle *h)
         h->copies_synced = need;
     }
     // d_in is reused by every launch: stream order makes its previous reader finish first (the cascade or the fused
-    // wideband kernel on h->stream; in the two-kernel wideband form the channeliser on stream3, which is why the copy
-    // goes there then).  Runs of neighbouring participants that fill the same set go as one 2-D copy.
-    hipStream_t cs = on_stream3 ? h->stream3 : h->stream;
+    // wideband kernel on h->stream).  Runs of neighbouring participants that fill the same set go as one 2-D copy.
+    hipStream_t cs = h->stream;
+    if (tail_n3)                                         // what lies behind a stream's last sample is not signal: zeros, for determinism
+        for (int s : part) memset(h->h_stage[h->cur[s]] + (size_t)s * h->stage_cap + h->fill[s], 0, (take - h->fill[s]) * 4);
     for (size_t i = 0; i < part.size();) {
         size_t j = i + 1;
         while (j < part.size() && part[j] == part[j - 1] + 1 && h->cur[part[j]] == h->cur[part[i]]) j++;
@@ -77,13 +86,13 @@ static int submit_locked(nvx_handle *h)
     HIP_TRY(hipEventRecord(r.copied, cs));           // (re-recording an event a later wait may still name: see above)
     const uint64_t this_launch = h->launched + 1;
     const bool all = (int)part.size() == h->n_in;
-    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, on_stream3, all ? nullptr : part.data(), all ? 0 : (int)part.size());
+    int rc = nvx_launch_locked(h, h->d_in, dpitch, 0, frames, h->stream, (all && !tail_n3) ? nullptr : part.data(), (all && !tail_n3) ? 0 : (int)part.size(), tail_n3);
     if (rc != NVX_OK) return rc;
     // what was not submitted moves over to the participant's other set, which it fills from now on
     for (int s : part) {
         const int c = h->cur[s], n = c ^ 1;
         h->set_launch[c][s] = this_launch;
-        const size_t rest = h->fill[s] - take;
+        const size_t rest = tail_n3 ? 0 : h->fill[s] - take;
         if (rest) memcpy(h->h_stage[n] + (size_t)s * h->stage_cap, h->h_stage[c] + (size_t)s * h->stage_cap + take, rest * 4);
         h->fill[s] = rest;
         h->cur[s] = (uint8_t)n;
@@ -102,6 +111,8 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::unique_lock<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);
+    if (h->ended[stream]) { nvx_set_error("nvx_push: stream %d has ended (nvx_finish); nvx_reset starts a new one", stream); return NVX_ERR_STATE; }
     HIP_TRY(hipSetDevice(h->cfg.device));
     // a stream has ONE pusher at a time, for the whole call (the lock is released while this one waits for a launch or
     // copies a large chunk: a second pusher of the same stream must not interleave its chunks with this one's)
@@ -126,12 +137,6 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
             // this stream is max_frames + 1 frames ahead of a launch: go with the streams that have a frame
             int rc = launch_if([&] { return h->fill[stream] == h->stage_cap; });
             if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
-            room = h->stage_cap - h->fill[stream];
-            if (room == 0) {                         // only the two-kernel wideband form gets here
-                nvx_set_error("stream %d is a whole staging buffer ahead of the slowest stream", stream);
-                if (accepted) *accepted = done;
-                return NVX_ERR_FULL;
-            }
             continue;                                // (the wait above released the lock: look again)
         }
         const size_t m = std::min(room, n - done);
@@ -184,22 +189,74 @@ extern "C" int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, con
     });
 }
 
+// whatever is staged in whole frames goes out, stream by stream as far as each has got (staging quiesced by the caller)
+static int submit_whole_frames_locked(nvx_handle *h)
+{
+    for (;;) {
+        const uint64_t before = h->launched;
+        int rc = submit_locked(h);
+        if (rc != NVX_OK) return rc;
+        if (h->launched == before) return NVX_OK;
+    }
+}
+
 extern "C" int nvx_flush(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
     std::unique_lock<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->cfg.push_mode) {
         StagingQuiesce quiet(h, lk);                 // pushes in flight on other threads commit first
-        // whatever is staged in whole frames goes out, stream by stream as far as each has got
-        for (;;) {
-            const uint64_t before = h->launched;
-            int rc = submit_locked(h);
+        int rc = submit_whole_frames_locked(h);
+        if (rc != NVX_OK) return rc;
+    }
+    return nvx_collect_locked(h);
+}
+
+// End of input (header: nvx_finish).  The reference's loop hands every sample it is given to sample_in_1 and stops
+// (receiver/capt_sched.c:509-513); its decoder has then seen floor(n / 280) samples at 900 S/s (y3[k] is complete
+// with input sample 280 k + 279) and decided the bits those samples decide (receiver/decoder.C:73-137) -- no more.  So:
+// whole frames go out as in nvx_flush; then ONE launch carries the streams that still hold a partial frame, each with its
+// true count of 900 S/s samples: the cascade runs the frame (zeros behind the last sample; every y3[k] with k below the
+// count depends on real samples only), the demodulator stops at the count.  stream < 0: every stream.
+static int finish_locked(nvx_handle *h, std::unique_lock<std::mutex> &lk, int stream)
+{
+    if (h->poisoned) return nvx_poisoned_error(h);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->cfg.push_mode) {
+        StagingQuiesce quiet(h, lk);
+        int rc = submit_whole_frames_locked(h);
+        if (rc != NVX_OK) return rc;
+        const size_t per_y3 = (h->cfg.raw_rate || h->cfg.wideband) ? (size_t)(280 * NVX_DECIM0) : (size_t)280;     // input samples per 900 S/s sample
+        std::vector<int> part, n3;
+        for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? h->n_in : stream + 1); s++) {
+            if (h->ended[s] || h->fill[s] == 0) continue;                 // (a stream that ends on a frame boundary simply goes on later)
+            const int t = (int)(h->fill[s] / per_y3);
+            if (t > 0) { part.push_back(s); n3.push_back(t); }
+            else { h->fill[s] = 0; h->ended[s] = 1; h->active[s] = 0; }  // too short for one more 900 S/s sample: nothing to decode
+        }
+        if (!part.empty()) {
+            rc = submit_part_locked(h, part, 1, n3.data());
             if (rc != NVX_OK) return rc;
-            if (h->launched == before) break;
+            for (int s : part) h->active[s] = 0;                         // nobody waits for an ended stream
         }
     }
     return nvx_collect_locked(h);
+}
+
+extern "C" int nvx_finish(nvx_handle *h)
+{
+    if (!h) return NVX_ERR_ARG;
+    std::unique_lock<std::mutex> lk(h->mu);
+    return finish_locked(h, lk, -1);
+}
+
+extern "C" int nvx_stream_finish(nvx_handle *h, int stream)
+{
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_finish: bad stream"); return NVX_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(h->mu);
+    return finish_locked(h, lk, stream);
 }
 
 // ------------------------------------------------------------------ WAV path
@@ -225,15 +282,9 @@ extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
     }
     nvx_wav_close(w);
     if (rc != NVX_OK) return rc;
-    size_t pad = (h->frame_in - total % h->frame_in) % h->frame_in;       // silence up to a whole frame
-    std::fill(buf.begin(), buf.end(), (int16_t)0);
-    while (pad) {
-        size_t m = std::min<size_t>(pad, 65536);
-        rc = nvx_push_iq(h, stream, buf.data(), m);
-        if (rc != NVX_OK) return rc;
-        pad -= m;
-    }
-    rc = nvx_flush(h);
+    // the file has ended: its last, partial frame runs at its true length (no padding: the reference's loop stops with the
+    // last sample, receiver/capt_sched.c:509-513)
+    rc = nvx_stream_finish(h, stream);
     if (rc != NVX_OK) return rc;
     return (int)((total + h->frame_in - 1) / h->frame_in);
 }

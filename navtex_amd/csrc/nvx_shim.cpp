@@ -155,6 +155,14 @@ extern "C" int nvx_shim_flush(void)
     return nvx_flush(g_shim);
 }
 
+extern "C" int nvx_shim_finish(void)
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    if (!g_shim) { nvx_set_error("shim not initialised"); return NVX_ERR_STATE; }
+    shim_drain();
+    return nvx_finish(g_shim);                   // the last, partial frame at its true length (capt_sched.c:509-513 stops with its last sample)
+}
+
 extern "C" size_t nvx_shim_bits(int chain, char *out, size_t cap)
 {
     if (!g_shim) return 0;
@@ -167,7 +175,7 @@ extern "C" void nvx_StreamACallback(short *xi, short *xq, void *params, unsigned
     (void)params; (void)reset;                   // ignored by the reference too (capt_sched.c:105-148)
     std::lock_guard<std::mutex> lk(g_shim_mu);
     nvx_handle *h = (nvx_handle *)cbContext;
-    if (!h) {
+    if (!h || h == g_shim) {                     // the singleton, named or not: its samples count for nvx_shim_latency
         const int64_t t_enter = nvx_now_ns();
         shim_require(); shim_drain(); h = g_shim;
         for (uint64_t f = g_shim_samples / NVX_FRAME_IN; f < (g_shim_samples + numSamples) / NVX_FRAME_IN; f++) g_shim_clock.stamp(f, t_enter);

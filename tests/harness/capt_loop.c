@@ -18,7 +18,7 @@
 void init_fir_filter1();
 void sample_in_1(double sample_I, double sample_Q);
 void init_fir2_wrapper();
-int nvx_shim_flush(void);          /* only so that a finite file can be finished */
+int nvx_shim_finish(void);         /* only so that a finite file can be finished: its last, partial frame at its true length */
 
 int add_message(char *bbbb, char *message, int freq)
 {
@@ -89,5 +89,5 @@ int main(int argc, char **argv)
     /* "noflush": what an unmodified capt_sched.c does -- it never flushes.  The messages of every launched frame must
      * still reach add_message (the library's housekeeping takes finished work in: 2 ms after a launch went out, every 50 ms otherwise); give it a moment. */
     if (argc > 2 && !strcmp(argv[2], "noflush")) { usleep(1500000); return 0; }
-    return nvx_shim_flush() == 0 ? 0 : 1;
+    return nvx_shim_finish() == 0 ? 0 : 1;
 }

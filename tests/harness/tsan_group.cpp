@@ -51,6 +51,7 @@ extern "C" int nvx_process_resident(nvx_handle *h, const void *, size_t, size_t,
 }
 extern "C" int nvx_fetch_bits(nvx_handle *h) { std::lock_guard<std::mutex> lk(h->mu); Stand &s = stand(h); deliver(h, s, s.launched); return NVX_OK; }
 extern "C" int nvx_flush(nvx_handle *h) { return nvx_fetch_bits(h); }
+extern "C" int nvx_finish(nvx_handle *h) { return nvx_fetch_bits(h); }
 extern "C" int nvx_reset(nvx_handle *h) { std::lock_guard<std::mutex> lk(h->mu); Stand &s = stand(h); s.launched = s.delivered = 0; return NVX_OK; }
 static std::atomic<int> g_in_push{ 0 }, g_overlapped{ 0 };                  // how many pushes are inside a handle at once
 extern "C" int nvx_push_iq(nvx_handle *h, int stream, const int16_t *, size_t)

@@ -22,36 +22,138 @@ def pad_to_frame(nv, iq):
     return np.vstack([iq, np.zeros((pad, 2), dtype=np.int16)]) if pad else iq
 
 
+def gold_messages(rec):
+    return sorted(rec["messages"])
+
+
+def got_messages(p):
+    return sorted([f, b, m] for (_s, f, b, m) in p.messages)
+
+
 @pytest.mark.parametrize("name", sorted(GOLD["iq"]))
 def test_reference_bits_reproduced_on_gpu(nv, name):
-    """Every golden case (clean, weak, offset, noise, silence, DC, full-scale random,
-    ragged length): the bits the compiled reference produced, bit for bit.  The tail is
-    zero-padded to a whole frame, so the GPU may decode a few extra bits after the end."""
+    """Every golden case (clean, weak, offset, noise, silence, DC, full-scale random, ragged length): the bits and the
+    messages the compiled reference produced from exactly these samples -- no more, no fewer.  The input is pushed as it
+    is, whatever its length; nvx_finish runs the last, partial frame at its true length (the reference's loop stops with
+    its last sample: receiver/capt_sched.c:509-513)."""
     rec = GOLD["iq"][name]
     iq = cases.make_iq(nv, rec["spec"])
     with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=8, push_mode=True) as p:
-        p.push(0, pad_to_frame(nv, iq))
-        p.flush()
+        p.push(0, iq)
+        p.finish()
         for tag, chain in (("518", 0), ("490", 1)):
-            want = rec[f"bits{tag}"]
-            got = p.bits(0, chain)
-            assert got[: len(want)] == want, f"{name}/{tag}"
-            assert len(got) - len(want) <= 40
-        if iq.shape[0] % nv.FRAME_IN == 0:
-            assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
+            assert p.bits(0, chain) == rec[f"bits{tag}"], f"{name}/{tag}"
+        assert got_messages(p) == gold_messages(rec)
+        if iq.shape[0] % nv.FRAME_IN:                # the stream has ended: nothing more goes in until a reset
+            with pytest.raises(nv.NvxError):
+                p.push(0, iq[:100])
+            p.reset()
+            p.push(0, iq); p.finish()
+            assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
+
+
+@pytest.mark.parametrize("name", ["ragged_length", "two_carrier", "weak_518"])
+def test_flush_keeps_a_partial_frame_staged_and_finish_ends_the_stream(nv, name):
+    """A streaming handle: arbitrary push sizes, plain nvx_flush calls in between (a partial frame stays staged and the
+    stream goes on bit-exactly), nvx_finish at the end -- bits and messages equal to the compiled reference's at every
+    cut, and the bits present after each flush are a prefix of the final ones."""
+    rec = GOLD["iq"][name]
+    iq = cases.make_iq(nv, rec["spec"])
+    rng = np.random.default_rng(len(name))
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=3, push_mode=True) as p:
+        pos, seen = 0, ["", ""]
+        while pos < iq.shape[0]:
+            m = int(min(iq.shape[0] - pos, rng.integers(1, 2 * nv.FRAME_IN)))
+            p.push(0, iq[pos:pos + m]); pos += m
+            if rng.integers(0, 3) == 0:
+                p.flush()
+                for c in (0, 1):
+                    now = p.bits(0, c)
+                    assert now.startswith(seen[c]); seen[c] = now
+        p.finish()
+        assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
+        assert p.bits(0, 0).startswith(seen[0]) and p.bits(0, 1).startswith(seen[1])
+        assert got_messages(p) == gold_messages(rec)
+
+
+@pytest.mark.parametrize("cut", [0, 1, 279, 280, 281, 2519, 2520, 9 * 280 + 5, 17 * 280, 40000, 80639])
+def test_every_kind_of_tail_matches_the_oracle(nv, oracle, cut):
+    """The end of a stream at every kind of position: nothing, less than one 900 S/s sample, exactly one, whole and ragged
+    bit periods, almost a frame -- after two whole frames and well past the demodulator's priming (the timing filter is
+    primed at 900 S/s sample 582, a frame is 288).  Bits == the oracle fed exactly the same samples."""
+    import signals
+    st, _ = signals.stream_params(nv, 5, nv.RATE_IN)
+    n = 3 * nv.FRAME_IN + cut
+    iq = nv.synth_host(st, nv.RATE_IN, n)
+    ref = oracle.Pipe(chain_mask=3, charlayer=False)
+    ref.push(iq)
+    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=2, push_mode=True, char_layer=False) as p:
+        p.push(0, iq)
+        p.finish()
+        assert p.bits(0, 0) == ref.bits(0) and p.bits(0, 1) == ref.bits(1)
+        assert len(ref.bits(0)) >= 28
+
+
+def test_tails_of_many_streams_in_one_launch_raw_rate_and_wideband(nv, oracle):
+    """nvx_finish on handles with several streams whose inputs end at different places (one on a frame boundary, one too
+    short for a single 900 S/s sample more): ONE launch carries every tail at its own length.  Both stage-0 forms at
+    2.016 MS/s, and a wideband handle (8 sub-bands x 2 chains per input).  Every chain == the oracle on the same samples;
+    the stream that ended on a frame boundary goes on afterwards, the others are ended."""
+    import signals
+    tails = [0, 2239, 2240, 100001, 300000, 645119]
+    for order in (1, 3):
+        with nv.Pipeline(n_streams=len(tails), raw_rate=True, chain_mask=3, max_frames=2, push_mode=True, char_layer=False, stage0_order=order) as p:
+            want = []
+            for s, t in enumerate(tails):
+                st, _ = signals.stream_params(nv, 20 + s, nv.RATE_RAW)
+                iq = nv.synth_host(st, nv.RATE_RAW, 3 * nv.FRAME_RAW + t)
+                ref = oracle.Pipe(chain_mask=3, charlayer=False); ref.set_stage0(order)
+                ref.push_raw(iq[: iq.shape[0] // 8 * 8])
+                want.append((ref.bits(0), ref.bits(1)))
+                p.push(s, iq)
+            launches0 = p.stream_stats(0)[2]
+            p.finish()
+            for s in range(len(tails)):
+                assert (p.bits(s, 0), p.bits(s, 1)) == want[s], f"stage0 order {order}, stream {s}"
+            for s, t in enumerate(tails):
+                if t == 0:
+                    p.push(s, np.zeros((16, 2), dtype=np.int16))          # not ended
+                else:
+                    with pytest.raises(nv.NvxError):
+                        p.push(s, np.zeros((16, 2), dtype=np.int16))
+    # wideband: two inputs, different tails
+    wt = [7 * 2240 * 9 + 3, 400000]
+    with nv.Pipeline(n_streams=2, wideband=True, chain_mask=3, max_frames=2, push_mode=True, char_layer=False) as p:
+        raws = []
+        for w, t in enumerate(wt):
+            car = [dict(freq_hz=(k * 252000 if k < 4 else (k - 8) * 252000) + off, bits=nv.sitor_encode(f"ZCZC WT{k}{c}\nTAIL\nNNNN\n", 4),
+                        bit_offset=977 * (2 * k + c + 1) + 31 * w, phase0=k * 1234567 + c, amplitude=1800) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
+            raw = nv.synth_host(nv.make_stream(car, seed=90 + w, noise_amp=300), nv.RATE_RAW, 3 * nv.FRAME_RAW + t)
+            raws.append(raw)
+            p.push(w, raw)
+        p.finish()
+        for w, raw in enumerate(raws):
+            sub = oracle.channelise(raw[: raw.shape[0] // 8 * 8])
+            for k in range(8):
+                ref = oracle.Pipe(chain_mask=3, charlayer=False)
+                ref.push(sub[k])
+                for c in (0, 1):
+                    assert p.bits(8 * w + k, c) == ref.bits(c), f"wideband input {w} band {k} chain {c}"
 
 
 def test_wav_file_path_config0(nv, tmp_path):
-    """configs[0]/[1] plumbing: 2-channel 16-bit 252 kHz WAV -> nvx_decode_wav -> messages."""
-    rec = GOLD["iq"]["two_carrier"]
-    iq = cases.make_iq(nv, rec["spec"])
-    path = str(tmp_path / "capture.wav")
-    nv.wav_write(path, iq, nv.RATE_IN)
-    with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True) as p:
-        frames = p.decode_wav(path)
-        assert frames == -(-iq.shape[0] // nv.FRAME_IN)
-        assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
-        assert p.bits(0, 0)[: len(rec["bits518"])] == rec["bits518"]
+    """configs[0]/[1] plumbing: 2-channel 16-bit 252 kHz WAV -> nvx_decode_wav -> bits and messages, exactly the compiled
+    reference's on the same samples (the file's last, partial frame runs at its true length); also a file of ragged length."""
+    for name in ("two_carrier", "ragged_length"):
+        rec = GOLD["iq"][name]
+        iq = cases.make_iq(nv, rec["spec"])
+        path = str(tmp_path / f"{name}.wav")
+        nv.wav_write(path, iq, nv.RATE_IN)
+        with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True) as p:
+            frames = p.decode_wav(path)
+            assert frames == -(-iq.shape[0] // nv.FRAME_IN)
+            assert got_messages(p) == gold_messages(rec)
+            assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
     with nv.Pipeline(n_streams=1, raw_rate=True, max_frames=1, push_mode=True) as p:
         with pytest.raises(nv.NvxError):          # wrong sample rate for this handle
             p.decode_wav(path)
@@ -80,7 +182,7 @@ def test_capture_loop_program_links_and_decodes(nv, tmp_path):
     """The reference-shaped main program (tests/harness/capt_loop.c: capt_sched.c's ring,
     callback and consumer loop, its own add_message) linked against libnavtex_amd.so."""
     rec = GOLD["iq"]["two_carrier"]
-    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    iq = cases.make_iq(nv, rec["spec"])              # as it is: the program ends the stream with nvx_shim_finish
     data = tmp_path / "iq.bin"
     iq.tofile(data)
     exe = tmp_path / "capt_loop"
@@ -129,7 +231,7 @@ def test_singleton_prints_the_reference_trace_when_asked(nv, tmp_path):
     def run(case, trace):
         rec = GOLD["iq"][case]
         data = tmp_path / f"{case}.bin"
-        pad_to_frame(nv, cases.make_iq(nv, rec["spec"])).tofile(data)
+        cases.make_iq(nv, rec["spec"]).tofile(data)
         env = dict(os.environ, NAVTEX_AMD_TRACE="1") if trace else {k: v for k, v in os.environ.items() if k != "NAVTEX_AMD_TRACE"}
         return rec, subprocess.run([str(exe), str(data)], check=True, capture_output=True, text=True, timeout=300, env=env).stdout
 

@@ -196,9 +196,6 @@ def test_a_paused_capture_ring_does_not_hold_the_other(nv, oracle):
 def test_wideband_streams_advance_independently(nv, oracle):
     """The same for a wideband handle (fused kernel): two 2.016 MS/s inputs, 16 carriers each; input 1 is late.  The
     launches carry a list of WIDEBAND streams; sub-band state and the 40-sample channeliser halo follow each stream's own parity."""
-    import os
-    if os.environ.get("NVX_WB_FUSED", "1") == "0":
-        pytest.skip("the two-kernel A/B form launches all streams together")
     F = 4
     n = F * nv.FRAME_RAW
     raws = []
@@ -341,9 +338,6 @@ def test_randomized_ragged_wideband_inputs(nv, oracle, seed):
     """The fused wideband kernel with participant lists, randomised: two or three 2.016 MS/s inputs (16 carriers each) fed
     in random order with random chunk sizes and silent spells; sub-band filter state and the channeliser's 40-sample halo
     follow each input's own parity.  All carriers == the restatement chain."""
-    import os
-    if os.environ.get("NVX_WB_FUSED", "1") == "0":
-        pytest.skip("the two-kernel A/B form launches all streams together")
     rng = np.random.default_rng(500 + seed)
     W, F, maxf = int(rng.integers(2, 4)), int(rng.integers(4, 7)), int(rng.integers(1, 3))
     n = F * nv.FRAME_RAW

@@ -215,3 +215,44 @@ def test_injected_stale_hand_overs_are_caught_repaired_and_counted():
         assert all(c["stale"] > 0 for c in rec["cases"] if c["kind"] == kind), rec
     deep = [c for c in rec["cases"] if c["kind"] == "list" and c.get("deep")]
     assert len(deep) == 4 and all(c["stale"] > 0 and c["partial_launches"] > 0 for c in deep), rec
+
+
+def test_a_failed_launch_poisons_the_handle_until_reset(nv, oracle):
+    """A launch whose inherited state fails its seal does not only lose its own bits.  The unit that found the bad block ran
+    on and sealed what it computed from it, the demodulator state moved on, and the launches already QUEUED behind it
+    inherit both under valid seals -- their bits are garbage that nothing else would ever flag.  So the failure sticks:
+    with three launches queued behind a corrupted block not one bit of any of them arrives; every later launch, push,
+    poll, fetch and flush answers NVX_ERR_STATE; nvx_reset recovers, and the handle then decodes the same input bit-exactly."""
+    n_frames = 8
+    st, _ = signals.stream_params(nv, 3, nv.RATE_IN)
+    iq = nv.synth_host(st, nv.RATE_IN, n_frames * nv.FRAME_IN)
+    ref = oracle.Pipe(chain_mask=1, charlayer=False)
+    ref.push(iq)
+    buf = nv.DeviceBuffer(iq.nbytes)
+    buf.upload(iq)
+    got_msgs = []
+    with nv.Pipeline(n_streams=1, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=True) as p:
+        p.process_resident(buf, n_frames * nv.FRAME_IN, 0, 2); p.fetch()
+        before = p.bit_count(0, 0)
+        blk = p.debug_state(0)
+        blk[40] ^= np.uint64(1) << np.uint64(17)
+        p.debug_set_state(0, blk)
+        for f in (2, 4, 6):                                    # three launches queued: the first inherits the bad block
+            p.process_resident(buf, n_frames * nv.FRAME_IN, f, 2)
+        with pytest.raises(nv.NvxError, match="integrity") as e:
+            p.fetch()
+        assert e.value.code == nv._native.ERR_HIP
+        assert p.bit_count(0, 0) == before and p.integrity_stats()[1] == 1
+        # everything answers "reset me" from here on, and still nothing arrives
+        for call in (lambda: p.process_resident(buf, n_frames * nv.FRAME_IN, 0, 1), lambda: p.push(0, iq[:1000]), p.poll, p.fetch, p.flush, p.finish):
+            with pytest.raises(nv.NvxError, match="nvx_reset") as e:
+                call()
+            assert e.value.code == nv._native.ERR_STATE
+        assert p.bit_count(0, 0) == before
+        p.reset()
+        for f in (0, 2, 4, 6):
+            p.process_resident(buf, n_frames * nv.FRAME_IN, f, 2)
+        p.fetch()
+        assert p.bits(0, 0) == ref.bits(0) and len(ref.bits(0)) > 150
+        assert p.integrity_stats()[:2] == (0, 1)
+    buf.free()

@@ -327,6 +327,67 @@ print(h.hexdigest())
     assert digests[0] == digests[1] == digests[2] and len(digests[0]) == 64
 
 
+def test_full_scale_rails_through_the_raw_rate_stage0(nv, tmp_path):
+    """The headline kernel's own stage 0 (SDWA half-word adds over the packed int16 pairs, nvx_cascade.hip) at the int16
+    rails: uniform random samples over the whole range with stretches of +32767 and of -32768 on both components, mixed
+    stretches and alternating rails (the sums of eight reach +-262 144 and round to the rails), through the one-chain and
+    the two-chain raw-rate kernels, in the hand-over form (waiting and pre-rolling) and with independent units: the
+    complete 900 S/s output as bit patterns and the bits == the oracle's raw-rate pipe (stage replaced:
+    receiver/capt_sched.c:412-413, the vendor's /8 decimation; first consumer receiver/fir1cpp.C:80-136)."""
+    import subprocess, sys, os
+    script = tmp_path / "rails.py"
+    script.write_text('''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np, navtex_amd as nv, oracle_binding as ob
+F, F2 = 4, 2
+n = (F + F2) * nv.FRAME_RAW
+rng = np.random.default_rng(77)
+checked = 0
+for masks in ([1, 1, 2], [3, 2, 3]):
+    S = len(masks)
+    raw = rng.integers(-32768, 32768, size=(S, n, 2), dtype=np.int16)
+    for s in range(S):
+        at = 1000 + 977 * s
+        raw[s, at:at + 70000] = 32767                              # both components at the positive rail
+        raw[s, at + 100000:at + 170000] = -32768                   # ... the negative one
+        raw[s, at + 200000:at + 230000, 0] = 32767; raw[s, at + 200000:at + 230000, 1] = -32768
+        alt = np.where(np.arange(40000) & 1, 32767, -32768).astype(np.int16)
+        raw[s, at + 300000:at + 340000, 0] = alt; raw[s, at + 300000:at + 340000, 1] = -1 - alt      # alternating rails, opposite signs
+        # the rails across a frame (= unit) boundary and across the launch boundary
+        raw[s, nv.FRAME_RAW - 5000:nv.FRAME_RAW + 5000] = -32768
+        raw[s, F * nv.FRAME_RAW - 3000:F * nv.FRAME_RAW + 3000] = 32767
+    buf = nv.DeviceBuffer(S * n * 4)
+    buf.upload(raw)
+    with nv.Pipeline(n_streams=S, raw_rate=True, chain_masks=masks, max_frames=F, char_layer=False) as p:
+        refs = []
+        for s in range(S):
+            r = ob.Pipe(chain_mask=masks[s], charlayer=False, tap_y3=(F + F2) * nv.FRAME_Y3)
+            r.push_raw(raw[s])
+            refs.append(r)
+        for f0, k in ((0, F), (F, F2)):
+            p.process_resident(buf, n, f0, k); p.fetch()
+            for s in range(S):
+                for c in range(2):
+                    if (masks[s] >> c) & 1:
+                        want = np.ascontiguousarray(refs[s].y3(c)[f0 * nv.FRAME_Y3:(f0 + k) * nv.FRAME_Y3])
+                        got = p.debug_y3(s, c)
+                        assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)), (masks, s, c, f0)
+                        assert np.abs(want).max() > 10.0
+                        checked += 1
+        for s in range(S):
+            for c in range(2):
+                assert p.bits(s, c) == (refs[s].bits(c) if (masks[s] >> c) & 1 else ""), (masks, s, c)
+    buf.free()
+print("rails ok", checked)
+''')
+    root = str(Path(__file__).resolve().parent.parent)
+    for env in (dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="0"), dict(NVX_INDEPENDENT="0", NVX_DYNAMIC_PREROLL="1"), dict(NVX_INDEPENDENT="1"), {}):
+        out = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, (env, out.stderr[-3000:])
+        assert out.stdout.strip().splitlines()[-1] == "rails ok 16", env
+
+
 def _run_full_size_total(nv, oracle, S, F, ncpu):
     """All S streams of a configs[3]-shaped batch against the oracle, bit for bit; returns (checked, bad, seconds, ties)."""
     import fullsize
