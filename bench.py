@@ -238,10 +238,24 @@ def self_launch(args, script=None, argv=None) -> None:
     sys.exit(child.returncode)
 
 
+# the sources that define the roofline kernels' device code: a PMC record of their traffic holds for exactly these bytes
+KERNEL_SOURCES = ("nvx_cascade.hip", "nvx_cascade_wave.h", "nvx_kernels.h", "nvx_device.h", "nvx_tables.h")
+
+
+def kernel_source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(name.encode()); h.update((ROOT / "navtex_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def traffic_record(S: int, F: int, order: int):
     """(bytes per launch, where it comes from) from profiles/hbm_traffic.json: one PMC record per (streams, frames, stage-0
     order) -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes.  A
-    static record of this workload on an earlier box, not a measurement of this run; (None, why) for any other shape."""
+    static record of this workload on an earlier box, not a measurement of this run -- and only of the kernel it was taken
+    on: an entry carries the hash of the kernel's sources (KERNEL_SOURCES) at the time of the PMC passes, and a record of
+    other sources is not quoted.  (None, why) for any other shape or source."""
     tf = ROOT / "profiles" / "hbm_traffic.json"
     have = []
     try:
@@ -249,12 +263,16 @@ def traffic_record(S: int, F: int, order: int):
         for e in rec.get("entries", [rec] if "bytes_per_launch" in rec else []):
             have.append((e.get("streams"), e.get("frames"), e.get("stage0_order", 1)))
             if e.get("streams") == S and e.get("frames") == F and e.get("stage0_order", 1) == order:
-                return e.get("bytes_per_launch"), ("profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                                   f"not measured by this run; {e.get('source', '')})")
+                now = kernel_source_hash()
+                if e.get("kernel_source_sha256_16") != now:
+                    return None, (f"null: the PMC record in profiles/hbm_traffic.json was taken on kernel sources {e.get('kernel_source_sha256_16')}, "
+                                  f"these are {now} (tools/gpu_scripts/gpu_r05_final.sh collects a new one, tools/update_hbm_traffic.py writes it)")
+                return e.get("bytes_per_launch"), ("profiles/hbm_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on these "
+                                                   f"kernel sources ({now}), not measured by this run; {e.get('source', '')})")
     except Exception as e:
         return None, f"null: profiles/hbm_traffic.json unreadable ({type(e).__name__})"
     return None, (f"null: profiles/hbm_traffic.json holds PMC records of (streams, frames, stage-0 order) {have}, not of ({S}, {F}, {order}) "
-                  "(tools/gpu_scripts/gpu_r04_final.sh collects them)")
+                  "(tools/gpu_scripts/gpu_r05_final.sh collects them)")
 
 
 def cpu_model() -> str:

@@ -73,7 +73,7 @@ def build_lib(force: bool = False) -> Path:
         if force or _stale(o, [CSRC / src] + headers):
             jobs.append([hipcc, "-x", "hip", "--offload-arch=" + ARCH, "-std=c++17", "-Wall", "-Wno-unused-value", "-Wno-unused-result", *COMMON, "-c", CSRC / src, "-o", o])
         objs.append(o)
-    # the translation units are independent: compile them side by side (the cascade's 16 instantiations dominate)
+    # the translation units are independent: compile them side by side (the cascade's twelve kernels dominate)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         list(pool.map(_run, jobs))
     if force or _stale(LIB, objs):

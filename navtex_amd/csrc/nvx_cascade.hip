@@ -1,7 +1,7 @@
 // nvx_cascade.hip -- the roofline kernel of the NAVTEX receive path (gfx950).  The other kernels:
 // nvx_demod.hip, nvx_channelise.hip, nvx_wideband_fused.hip, nvx_synth.hip.
 //
-//   nvx_fir_cascade<RAW, NCH, PFD, NT>   int16 IQ in HBM -> 900 S/s complex fp64 per chain
+//   nvx_fir_cascade<RAW, NCH>            int16 IQ in HBM -> 900 S/s complex fp64 per chain
 //        stage 0 (/8 integer, build-owned, RAW only)
 //        FIR1 37 taps /4        receiver/fir1cpp.C:80-136
 //        mixer +-14 kHz         receiver/fir2cpp.C:112-128
@@ -69,9 +69,7 @@
 // component, hands the other one to its partner, and one DPP pair-swap add
 // completes both sums.  11 VALU instructions per load, ~34 issue cycles
 // (tools/valu_probe3.hip: SDWA and v_dot2c both issue in 4 cycles, plain VOP2
-// in 2; the earlier form, eight v_dot2c with per-lane selector registers, took
-// ~44).  -DNVX_STAGE0_DOT2C builds that earlier form for A/B runs.
-#ifndef NVX_STAGE0_DOT2C
+// in 2; the first form, eight v_dot2c with per-lane selector registers, took ~44: profiles/TUNING.md).
 __device__ __forceinline__ int add_low_halves(unsigned a, unsigned b)
 {
     int r;
@@ -96,24 +94,6 @@ __device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
     const int tot = mine + dpp_swap_pairs(other);             // DPP operand) from being merged into a v_mov_dpp + 4-cycle v_add3
     return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
 }
-#else
-__device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
-{
-    const nvx_short2 selI = { 1, 0 }, selQ = { 0, 1 };          // (1,0) picks I, (0,1) picks Q
-    const nvx_short2 sel_mine = odd ? selQ : selI, sel_other = odd ? selI : selQ;
-    int mine = 2, other = 2;                  // 2 + 2 = the +4 of round-half-up
-    mine  = __builtin_amdgcn_sdot2(as_short2(v.x), sel_mine,  mine,  false);
-    other = __builtin_amdgcn_sdot2(as_short2(v.x), sel_other, other, false);
-    mine  = __builtin_amdgcn_sdot2(as_short2(v.y), sel_mine,  mine,  false);
-    other = __builtin_amdgcn_sdot2(as_short2(v.y), sel_other, other, false);
-    mine  = __builtin_amdgcn_sdot2(as_short2(v.z), sel_mine,  mine,  false);
-    other = __builtin_amdgcn_sdot2(as_short2(v.z), sel_other, other, false);
-    mine  = __builtin_amdgcn_sdot2(as_short2(v.w), sel_mine,  mine,  false);
-    other = __builtin_amdgcn_sdot2(as_short2(v.w), sel_other, other, false);
-    const int tot = mine + dpp_swap_pairs(other);
-    return (double)(tot >> 3);                // arithmetic shift = floor((sum+4)/8)
-}
-#endif
 
 // Stage 0, third-order form (nvx_config.stage0_order = 3): three cascaded 8-sample boxcars decimated by 8, i.e. the
 // 22-tap filter w = 1 3 6 10 15 21 28 36 42 46 48 48 46 ... 3 1 (sum 512):  y[k] = (sum_j w[j] x[8k+7-j] + 256) >> 9.
@@ -165,15 +145,16 @@ struct Stage0Cic3 {
     }
 };
 
-template <bool RAW, bool NT>
+// One pass of input into registers: every byte is read once and never again, so the loads are non-temporal (plain
+// loads measured 1.4 % slower).  src already points at this lane's first 16 bytes of the pass.
+template <bool RAW>
 __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 *src)
 {
-    // src already points at this lane's first 16 bytes of the pass
     if (RAW) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) pf[j] = NT ? __builtin_nontemporal_load(src + 64 * j) : src[64 * j];
+        for (int j = 0; j < 8; j++) pf[j] = __builtin_nontemporal_load(src + 64 * j);
     } else {
-        pf[0] = NT ? __builtin_nontemporal_load(src) : src[0];
+        pf[0] = __builtin_nontemporal_load(src);
     }
 }
 
@@ -209,7 +190,7 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // time).  A kernel of its own, so that the launches of every stream -- the roofline configuration -- run exactly the
 // code they ran before lists existed (with the list test inside it the headline kernel was 0.8 % slower: 20.50 against
 // 20.34 ms, same box, interleaved, profiles/r03).
-template <bool RAW, int NCH, int PFD, bool NT, int S0, typename ARGS, bool LIST = false>
+template <bool RAW, int NCH, int S0, typename ARGS, bool LIST = false>
 __device__ __forceinline__ void cascade_wave_main(ARGS a)
 {
     __shared__ CascadeLds<NCH> lds;
@@ -273,8 +254,8 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         // the input does not depend on the predecessor: request the first pass now (of the unit itself; a unit that turns
         // out to need the pre-roll requests its real first pass again and lets this one go)
         const u32x4 *unit0 = (const u32x4 *)(a.iq + ((size_t)stream * a.pitch + a.first_sample)) + (size_t)part * NVX_THIRD_PASSES * pass_stride + lane;
-        u32x4 pfA[NPF], pfB[NPF];
-        if (!preroll) load_pass<RAW, NT>(pfA, unit0);
+        u32x4 pfA[NPF];
+        if (!preroll) load_pass<RAW>(pfA, unit0);
 
         // ------------------------------------------------------ wait for (stream, part-1)
         if (part > 0 && !a.independent) {
@@ -299,13 +280,7 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
                     if (lane == 0) __hip_atomic_store(a.status, NVX_STATUS_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-#ifdef NVX_HANDOFF_FENCES
-                // one agent-scope acquire per unit: the state lines may sit stale in this CU's L1
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
                 asm volatile("" ::: "memory");               // the state loads below stay below the flag poll
-#endif
             }
         }
 
@@ -351,9 +326,8 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         const int pre = preroll ? NVX_PREROLL_PASSES : 0;
         const int n_pass = pre + thirds * NVX_THIRD_PASSES;
         const u32x4 *src = unit0 - (size_t)pre * pass_stride;
-        if (preroll) load_pass<RAW, NT>(pfA, src);
-        if (PFD == 2) load_pass<RAW, NT>(pfB, src + pass_stride);
-        const u32x4 *nxt = src + PFD * pass_stride;    // first pass not yet requested
+        if (preroll) load_pass<RAW>(pfA, src);
+        const u32x4 *nxt = src + pass_stride;          // first pass not yet requested (one pass of prefetch; two measured null)
         // mixer index of the unit's first FIR1 output: 6720 * third mod 9 (0 at every frame start; the pre-roll starts
         // 576 = 0 mod 9 outputs earlier: same index); FIR3 outputs of the pre-roll are not written
         cw.begin_unit(mask, a.y3, (size_t)(stream * 2) * a.y3_cap + a.y3_base + (size_t)part * NVX_THIRD_Y3, a.y3_cap,
@@ -379,26 +353,17 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
                     xw4[r * XS] = v;
                 }
             }
-            // ---- 2. prefetch pass + PFD into the buffer just consumed --------------
-            if (pass + PFD < n_pass) load_pass<RAW, NT>(pf, nxt);
+            // ---- 2. prefetch the next pass into the buffer just consumed --------------
+            if (pass + 1 < n_pass) load_pass<RAW>(pf, nxt);
             nxt += pass_stride;
             NVX_WAVE_LDS_FENCE();
             // ---- 3.-7. FIR1, mixer, history slide, FIR2 / FIR3 when their batches are full
             cw.compute_pass();
         };
 
-        if (PFD == 2) {
-            for (int pass = 0; pass < n_pass; pass += 2) {
-                if (pass == pre) { cw.emit = true; cw.n3_done = 0; }
-                body(pfA, pass);
-                if (pass + 1 == pre) { cw.emit = true; cw.n3_done = 0; }
-                if (pass + 1 < n_pass) body(pfB, pass + 1);
-            }
-        } else {
-            for (int pass = 0; pass < n_pass; pass++) {
-                if (pass == pre) { cw.emit = true; cw.n3_done = 0; }
-                body(pfA, pass);
-            }
+        for (int pass = 0; pass < n_pass; pass++) {
+            if (pass == pre) { cw.emit = true; cw.n3_done = 0; }
+            body(pfA, pass);
         }
 
         // ------------------------------------------------------ state out
@@ -433,48 +398,46 @@ __device__ __forceinline__ void cascade_wave_main(ARGS a)
         }
         // publish: the state stores (write-through, sc1) have completed at device level once vmcnt is 0; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef NVX_HANDOFF_FENCES
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         if (lane == 0 && !a.independent) __hip_atomic_store(done, part + thirds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <bool RAW, int NCH, int PFD, bool NT>
+template <bool RAW, int NCH>
 __global__ __launch_bounds__(64) void nvx_fir_cascade(nvx_cascade_args a)
 {
-    if (RAW) cascade_wave_main<RAW, NCH, PFD, NT, 1, const nvx_cascade_args &>(a);
-    else cascade_wave_main<RAW, NCH, PFD, NT, 1, const nvx_cascade_args>(a);
+    if (RAW) cascade_wave_main<RAW, NCH, 1, const nvx_cascade_args &>(a);
+    else cascade_wave_main<RAW, NCH, 1, const nvx_cascade_args>(a);
 }
 
-// The raw-rate kernels with the third-order stage 0 (shipped configuration only: one pass of prefetch, nt loads).
-// The single-chain one is held to 168 VGPRs (it would take 171: two waves per SIMD instead of the three that make up
-// the 11 per CU its LDS allows); the compiler finds the three registers without spilling.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void nvx_fir_cascade_cic3_1(nvx_cascade_args a) { cascade_wave_main<true, 1, 1, true, 3, const nvx_cascade_args &>(a); }
-__global__ __launch_bounds__(64) void nvx_fir_cascade_cic3_2(nvx_cascade_args a) { cascade_wave_main<true, 2, 1, true, 3, const nvx_cascade_args &>(a); }
+// The raw-rate kernels with the third-order stage 0.  The single-chain one is held to 168 VGPRs (it would take 171: two
+// waves per SIMD instead of the three that make up the 11 per CU its LDS allows); the compiler finds the three registers
+// without spilling.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void nvx_fir_cascade_cic3_1(nvx_cascade_args a) { cascade_wave_main<true, 1, 3, const nvx_cascade_args &>(a); }
+__global__ __launch_bounds__(64) void nvx_fir_cascade_cic3_2(nvx_cascade_args a) { cascade_wave_main<true, 2, 3, const nvx_cascade_args &>(a); }
 
-// The same kernels for launches that name their streams (LIST; shipped configuration only: one pass of prefetch, nt loads).
+// The same kernels for launches that name their streams (LIST).
 template <bool RAW, int NCH, int S0>
 __global__ __launch_bounds__(64) void nvx_fir_cascade_list(nvx_cascade_args a)
 {
-    if (RAW) cascade_wave_main<RAW, NCH, 1, true, S0, const nvx_cascade_args &, true>(a);
-    else cascade_wave_main<RAW, NCH, 1, true, S0, const nvx_cascade_args, true>(a);
+    if (RAW) cascade_wave_main<RAW, NCH, S0, const nvx_cascade_args &, true>(a);
+    else cascade_wave_main<RAW, NCH, S0, const nvx_cascade_args, true>(a);
 }
 
-template <bool RAW, int NCH, int PFD, bool NT, int S0, bool LIST = false> struct CascadeKernel { static constexpr auto fn = nvx_fir_cascade<RAW, NCH, PFD, NT>; };
-template <> struct CascadeKernel<true, 1, 1, true, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_1; };
-template <> struct CascadeKernel<true, 2, 1, true, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_2; };
-template <bool RAW, int NCH, int S0> struct CascadeKernel<RAW, NCH, 1, true, S0, true> { static constexpr auto fn = nvx_fir_cascade_list<RAW, NCH, S0>; };
+// Twelve kernels in all, every one launched by the GPU suite (tests/test_isa.py lists them): {252 kS/s, raw rate} x {one,
+// two chains} x {every stream, list}, and for raw-rate input each of those once more with the third-order stage 0.
+template <bool RAW, int NCH, int S0, bool LIST> struct CascadeKernel { static constexpr auto fn = nvx_fir_cascade_list<RAW, NCH, S0>; };
+template <bool RAW, int NCH> struct CascadeKernel<RAW, NCH, 1, false> { static constexpr auto fn = nvx_fir_cascade<RAW, NCH>; };
+template <> struct CascadeKernel<true, 1, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_1; };
+template <> struct CascadeKernel<true, 2, 3, false> { static constexpr auto fn = nvx_fir_cascade_cic3_2; };
 
 // ===========================================================================
 // launcher (C linkage, called from the host runtime)
 // ===========================================================================
 #define NVX_MAX_DEVICES 64
-// tuning switches for A/B runs (defaults are the shipped configuration; read once per process)
+// test switches: both unit forms ship and the launcher picks one per launch; the suite forces each (read once per process)
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
-template <bool RAW, int NCH, int PFD, bool NT, int S0 = 1, bool LIST = false>
+template <bool RAW, int NCH, int S0 = 1, bool LIST = false>
 static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
 {
     // persistent grid: as many single-wave workgroups as the device of this launch holds at once (cached per device:
@@ -491,10 +454,8 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
         if (!cached) {
             int cus = 0, per_cu = 0;
             e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, CascadeKernel<RAW, NCH, PFD, NT, S0, LIST>::fn, 64, 0);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, CascadeKernel<RAW, NCH, S0, LIST>::fn, 64, 0);
             if (e != hipSuccess) return e;
-            const int cap = env_int("NVX_WAVES_PER_CU", 0);
-            if (cap > 0 && cap < per_cu) per_cu = cap;
             n_cus = cus; fit_per_cu = per_cu > 0 ? per_cu : 1;
             if (dev >= 0 && dev < NVX_MAX_DEVICES) { cus_of[dev] = n_cus; fit_of[dev] = fit_per_cu; }
         } else {
@@ -505,9 +466,6 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     if (a->max_waves_per_cu > 0 && a->max_waves_per_cu < per_cu) per_cu = a->max_waves_per_cu;
     if (a->max_waves_per_cu < 0 && per_cu + a->max_waves_per_cu >= 4) per_cu += a->max_waves_per_cu;     // "so many fewer than fit"
     const int resident = n_cus * per_cu;
-    // The last frame of a launch goes out in thirds when the launch is longer than one round of the grid: the waves that
-    // get no unit in the last round idle for a third of a frame instead of a whole one (4096 x 12: 4.1 % of all wave
-    // time was that idle tail).  NVX_TAIL_SPLIT=0: whole frames only; =n: the last n frames in thirds.
     nvx_cascade_args args = *a;
     // Fewer streams than resident waves: the units of one stream would run one after the other and most of the
     // chip would idle.  Then every unit rebuilds its filter histories from the nine passes in front of it
@@ -518,11 +476,9 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     // get no unit in the last round idle for a third of a frame instead of a whole one (4096 x 12: 4.1 % of all wave
     // time was that idle tail).  r3: a launch of independent units that leaves two thirds of the chip idle even so -- one
     // or a few channels replayed from a recording -- goes out in thirds THROUGHOUT: three times the units, each with its
-    // own nine-pass pre-roll (+8.6 % input), a third of the time.  NVX_TAIL_SPLIT=0: whole frames only; =n: the last n.
-    static const int tail_split = env_int("NVX_TAIL_SPLIT", -1);
+    // own nine-pass pre-roll (+8.6 % input), a third of the time.
     const long long whole_units = (long long)a->n_streams * a->n_frames;
-    int split_frames = tail_split >= 0 ? tail_split : (whole_units > resident ? 1 : ((args.independent && 3 * whole_units <= resident) ? a->n_frames : 0));
-    if (split_frames > a->n_frames) split_frames = a->n_frames;
+    const int split_frames = whole_units > resident ? 1 : ((args.independent && 3 * whole_units <= resident) ? a->n_frames : 0);
     args.split_from = a->n_frames - split_frames;
     const long long units = (long long)a->n_streams * (args.split_from + 3LL * split_frames);
     const unsigned grid = (unsigned)(units < resident ? units : resident);
@@ -530,29 +486,22 @@ static hipError_t launch_cascade_as(const nvx_cascade_args *a, hipStream_t s)
     // (NVX_DYNAMIC_PREROLL=0: it waits, as in round 1)
     static const int dynamic = env_int("NVX_DYNAMIC_PREROLL", 1);
     args.dynamic_preroll = dynamic != 0;
-    hipLaunchKernelGGL((CascadeKernel<RAW, NCH, PFD, NT, S0, LIST>::fn), dim3(grid), dim3(64), 0, s, args);
+    hipLaunchKernelGGL((CascadeKernel<RAW, NCH, S0, LIST>::fn), dim3(grid), dim3(64), 0, s, args);
     return hipGetLastError();
 }
 
 extern "C" hipError_t nvx_launch_cascade(const nvx_cascade_args *a, int raw, int nch, hipStream_t s)
 {
-    static const int pfd = env_int("NVX_PREFETCH", 1) == 2 ? 2 : 1;
-    static const int nt = env_int("NVX_NT", 1) != 0;
     // queue counter, status word and per-stream completion counts start at zero every launch
     hipError_t e = hipMemsetAsync(a->queue, 0, (size_t)(NVX_CASCADE_CTRL_INTS + a->n_streams) * sizeof(int), s);
     if (e != hipSuccess) return e;
-#define NVX_CASE(R, C) ( \
-        pfd == 2 ? (nt ? launch_cascade_as<R, C, 2, true>(a, s) : launch_cascade_as<R, C, 2, false>(a, s)) \
-                 : (nt ? launch_cascade_as<R, C, 1, true>(a, s) : launch_cascade_as<R, C, 1, false>(a, s)))
-    // launches that name their streams, and the third-order stage 0, exist in the shipped configuration only (one pass
-    // of prefetch, nt loads)
+    const bool cic3 = raw && a->stage0_order == 3;
     if (a->part) {
-        if (raw && a->stage0_order == 3) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 3, true>(a, s) : launch_cascade_as<true, 2, 1, true, 3, true>(a, s);
-        if (raw) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 1, true>(a, s) : launch_cascade_as<true, 2, 1, true, 1, true>(a, s);
-        return nch == 1 ? launch_cascade_as<false, 1, 1, true, 1, true>(a, s) : launch_cascade_as<false, 2, 1, true, 1, true>(a, s);
+        if (cic3) return nch == 1 ? launch_cascade_as<true, 1, 3, true>(a, s) : launch_cascade_as<true, 2, 3, true>(a, s);
+        if (raw) return nch == 1 ? launch_cascade_as<true, 1, 1, true>(a, s) : launch_cascade_as<true, 2, 1, true>(a, s);
+        return nch == 1 ? launch_cascade_as<false, 1, 1, true>(a, s) : launch_cascade_as<false, 2, 1, true>(a, s);
     }
-    if (raw && a->stage0_order == 3) return nch == 1 ? launch_cascade_as<true, 1, 1, true, 3>(a, s) : launch_cascade_as<true, 2, 1, true, 3>(a, s);
-    if (raw) return nch == 1 ? NVX_CASE(true, 1) : NVX_CASE(true, 2);
-    return nch == 1 ? NVX_CASE(false, 1) : NVX_CASE(false, 2);
-#undef NVX_CASE
+    if (cic3) return nch == 1 ? launch_cascade_as<true, 1, 3>(a, s) : launch_cascade_as<true, 2, 3>(a, s);
+    if (raw) return nch == 1 ? launch_cascade_as<true, 1>(a, s) : launch_cascade_as<true, 2>(a, s);
+    return nch == 1 ? launch_cascade_as<false, 1>(a, s) : launch_cascade_as<false, 2>(a, s);
 }

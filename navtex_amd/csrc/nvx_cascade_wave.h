@@ -35,9 +35,7 @@
 #define XH 5
 #define XS 37
 #define X_ENTRIES (XPH * XS)
-#ifndef NVX_Y2_RUN
-#define NVX_Y2_RUN 160                    /* single-chain kernel: FIR2 outputs per FIR3 run, 160 (16 outputs) or 80 */
-#endif
+#define NVX_Y2_RUN 160                    /* single-chain kernel: FIR2 outputs per FIR3 run (16 outputs x {I,Q} = 32 lanes) */
 
 // Batching geometry.  One chain: FIR2 runs on 224 pending mixer outputs (32 outputs x {I,Q} = 64
 // lanes), FIR3 on NVX_Y2_RUN pending FIR2 outputs.  Two chains: both chains share a run
@@ -68,19 +66,8 @@ template <int NCH, bool F3IN = true>
 struct CascadeLds : CascadeLdsY2<NCH, F3IN> {
     double2 X[X_ENTRIES];
     double2 U[NCH][GeoSizes<NCH>::U_ENTRIES];
-#ifndef NVX_MIX_GLOBAL
     double2 mix[2][2 * NVX_MIX_N];      // [sign of the cross term][two periods of (cos, -+sin)]
-#endif
 };
-
-#ifdef NVX_MIX_GLOBAL
-// A/B build: the mixer table in device memory instead of LDS (576 B less per wave: 13 312 B, 12 waves per CU instead of
-// 11); one 16-byte load per lane per pass, issued a pass ahead of its use.
-#define NVX_MIXE(j, S) { NVX_MIX_CR[(j) % NVX_MIX_N], S NVX_MIX_CI[(j) % NVX_MIX_N] }
-#define NVX_MIXROW(S) { NVX_MIXE(0, S), NVX_MIXE(1, S), NVX_MIXE(2, S), NVX_MIXE(3, S), NVX_MIXE(4, S), NVX_MIXE(5, S), NVX_MIXE(6, S), NVX_MIXE(7, S), NVX_MIXE(8, S), \
-                      NVX_MIXE(9, S), NVX_MIXE(10, S), NVX_MIXE(11, S), NVX_MIXE(12, S), NVX_MIXE(13, S), NVX_MIXE(14, S), NVX_MIXE(15, S), NVX_MIXE(16, S), NVX_MIXE(17, S) }
-static __device__ const double2 nvx_mix_global[2][2 * NVX_MIX_N] = { NVX_MIXROW(+), NVX_MIXROW(-) };
-#endif
 
 __device__ __forceinline__ int dpp_swap_pairs(int v)
 {
@@ -94,25 +81,9 @@ __device__ __forceinline__ double dpp_swap_pairs_f64(double v)
 
 // FIR1 window: s_j = x[8*half + 7 - j] is component comp of X[r * XS + XH + half + fl] with 7 - j = 8 * fl + r;
 // offset in doubles from the lane's base pointer
-#ifndef NVX_F1_GROUP
 #define NVX_F1_GROUP 4                    /* LDS reads per wait */
-#endif
-#ifndef NVX_F1_AHEAD
 #define NVX_F1_AHEAD 3                    /* groups in flight ahead of the arithmetic */
-#endif
-#ifndef NVX_F23_AHEAD
 #define NVX_F23_AHEAD 12                  /* FIR2 / FIR3: taps read ahead */
-#endif
-/* FIR2 / FIR3 tap i: a plain literal.  The compiler creates all 118 at kernel entry, parks most of them in VGPR lanes
- * (70 "SGPR spills") and fetches a tap back with two v_readlane in front of its multiply.  -DNVX_TAPS_INPLACE creates every
- * tap where it is used instead (two s_mov_b32, nvx_device.h): no spill, no v_readlane, 212 vector instructions fewer in
- * the pass loop's code -- and measured no faster (Variant A 75.3 vs 74.9-79 ms) or slower (fused wideband 19.6 vs 18.5 ms,
- * raw 21.0 vs 20.75): the count of instructions a wave issues is what it was, and they are 8 bytes each.  Kept for A/B. */
-#ifdef NVX_TAPS_INPLACE
-#define NVX_TAP(H, i) (nvx_scalar_f64<nvx_lo32(H[i]), nvx_hi32(H[i])>())
-#else
-#define NVX_TAP(H, i) (H[i])
-#endif
 __device__ __forceinline__ constexpr int f1_offset(int j)
 {
     const int t = 7 - j, r = t & 7, fl = (t - r) / 8;
@@ -158,7 +129,11 @@ __device__ __forceinline__ void state_store(double2 *p, double2 v)
 // ---- the state block's seal (nvx_kernels.h): every 8-byte pattern a unit stores, rotated by its position in the block
 // and XOR-folded over the wave, mixed with the block's tag (stream, position of the stream in thirds of a frame).
 // Position = (slot of the entry in the lane's list: a compile-time rotation) and (lane: the rotations of the butterfly
-// below) -- no lane-dependent shift counts, which the compiler would keep in VGPRs across the whole kernel (the
+// below), added mod 64: what the word is FOR is a stale or torn block -- a block of another position, stream or launch
+// (the tag), a block of which only part arrived -- and any single changed bit; it is not a cryptographic permutation
+// check (two words whose slot and lane rotations add up to the same total could be swapped unnoticed, and FIR3's history
+// of a wideband handle and the demodulator's carried state lie outside it: they only ever cross kernel boundaries).
+// No lane-dependent shift counts, which the compiler would keep in VGPRs across the whole kernel (the
 // headline kernel sits 9 registers under its occupancy limit).
 template <int R> __device__ __forceinline__ unsigned long long seal_rotc(unsigned long long v)
 {
@@ -201,13 +176,6 @@ __device__ __forceinline__ unsigned long long wave_fold64(unsigned long long v)
     const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
     return seal_row(lo, hi, 0) ^ seal_rotc<16>(seal_row(lo, hi, 16)) ^ seal_rotc<32>(seal_row(lo, hi, 32)) ^ seal_rotc<48>(seal_row(lo, hi, 48));
 }
-#ifdef NVX_SEAL_OFF
-// A/B build (what the seal costs): the blocks carry no seal and nothing is checked
-#define wave_fold64(v) (v)
-__device__ __forceinline__ void seal_store(double2 *, unsigned long long, int, unsigned) {}
-__device__ __forceinline__ unsigned long long seal_load(const double2 *) { return 0; }
-__device__ __forceinline__ bool seal_ok(unsigned long long, unsigned long long, int, unsigned) { return true; }
-#else
 // the seal entry: { fold ^ seal_tag, the tag in clear (diagnostics) }
 __device__ __forceinline__ void seal_store(double2 *st, unsigned long long fold, int stream, unsigned third)
 {
@@ -226,7 +194,6 @@ __device__ __forceinline__ bool seal_ok(unsigned long long got, unsigned long lo
     const unsigned long long d = got ^ fold ^ seal_tag(stream, third);
     return __builtin_amdgcn_readfirstlane((int)((unsigned)d | (unsigned)(d >> 32))) == 0;
 }
-#endif
 
 // One wave's share of the cascade.  lane = 2 * (pair / output index) + component, in stage 0, FIR1, the mixer, FIR2
 // and FIR3 alike.
@@ -235,11 +202,7 @@ struct CascadeWave {
     CascadeLds<NCH, F3IN> *lds;
     int lane, half, comp;
     const lds_vdouble *xrv;              // FIR1 read base: sample 8*half + t is component comp of X[(t & 7) * XS + XH + half + floor(t / 8)]
-#ifdef NVX_MIX_GLOBAL
-    const nvx_d2 *mixrow;                // this lane's row of the mixer table in device memory (set per unit)
-#else
     const lds_vd2 *mixrow;               // this lane's row of the mixer table (set per unit)
-#endif
     int lane_mod9;
     double h1v[NVX_T1];
     // per unit
@@ -259,7 +222,6 @@ struct CascadeWave {
         lds = l; lane = lane_; half = lane >> 1; comp = lane & 1;
         xrv = (const lds_vdouble *)((const double *)&lds->X[XH + half] + comp);
         lane_mod9 = (2 * half) % 9;
-#ifndef NVX_MIX_GLOBAL
         if (lane < 4 * NVX_MIX_N) {
             // constant-index selects keep the tables out of scratch
             const int j9 = lane % NVX_MIX_N;
@@ -269,7 +231,6 @@ struct CascadeWave {
             lds->mix[0][lane % (2 * NVX_MIX_N)] = double2{ cr, ci };      // both copies are written by two lanes each: same value
             lds->mix[1][lane % (2 * NVX_MIX_N)] = double2{ cr, -ci };
         }
-#endif
 #pragma unroll
         for (int i = 0; i < NVX_T1; i++)
             if (NVX_H1_FIRST.first[i] == i) { h1v[i] = NVX_H1[i]; asm volatile("" : "+v"(h1v[i])); }
@@ -287,11 +248,7 @@ struct CascadeWave {
         set_mask(chain_mask);
         // mixer table row of this lane: its cross term carries the sign of the 518 chain (I lanes negated) -- or, when the
         // unit's only chain is the 490 one, of that chain (Q lanes negated); see step 4
-#ifdef NVX_MIX_GLOBAL
-        mixrow = (const nvx_d2 *)&nvx_mix_global[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
-#else
         mixrow = (const lds_vd2 *)&lds->mix[(comp ^ (NCH == 1 ? chain_of_slot0 : 0)) ? 0 : 1][lane_mod9];
-#endif
         y3 = y3_; y3_row0 = row0; y3_cap = cap;
         mixbase = mixbase0; n_u = n_u0; n_y2 = n_y20; n3_done = 0; n2_done = 0; emit = emit0;
         mix_next = mixrow[mixbase];      // (behind init()'s table writes in this wave's LDS queue)
@@ -457,7 +414,7 @@ struct CascadeWave {
                 nvx_static_for<0, NVX_T2>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     if constexpr (i + NVX_F23_AHEAD < NVX_T2) { NVX_PIN_AFTER(acc); xs2[i + NVX_F23_AHEAD] = ub[2 * (52 - (i + NVX_F23_AHEAD))]; }
-                    acc += NVX_TAP(NVX_H2, i) * xs2[i];
+                    acc += NVX_H2[i] * xs2[i];
                 });
                 if constexpr (F3IN) {
                     if (NCH == 1 || ((mask >> f2c) & 1u)) ((double *)&lds->Y2[f2c][70 + n_y2 + f2o])[comp] = acc;
@@ -501,7 +458,7 @@ struct CascadeWave {
                     nvx_static_for<0, NVX_T3>([&](auto ic) {
                         constexpr int i = decltype(ic)::value;
                         if constexpr (i + NVX_F23_AHEAD < NVX_T3) { NVX_PIN_AFTER(acc); xs3[i + NVX_F23_AHEAD] = yb[2 * (79 - (i + NVX_F23_AHEAD))]; }
-                        acc += NVX_TAP(NVX_H3, i) * xs3[i];
+                        acc += NVX_H3[i] * xs3[i];
                     });
                     if (emit && f3live && (NCH == 1 || ((mask >> f3c) & 1u))) {
                         double *out = (double *)(y3 + (y3_row0 + (size_t)ch * y3_cap + n3_done + f3o));

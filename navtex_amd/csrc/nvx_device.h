@@ -23,18 +23,6 @@ typedef __attribute__((address_space(3))) volatile nvx_d2 lds_vd2;          // o
 // scheduler hoists every LDS read of an unrolled FIR to the top of the block and the kernel needs 140 more VGPRs.
 #define NVX_PIN_AFTER(v) asm volatile("" : "+v"(v))
 
-// A 64-bit constant in a scalar register pair, materialised (two s_mov_b32) where it is used; the asm is volatile so
-// that it stays there.  Used by the -DNVX_TAPS_INPLACE build of the cascade (nvx_cascade_wave.h, NVX_TAP).
-template <unsigned LO, unsigned HI>
-__device__ __forceinline__ double nvx_scalar_f64()
-{
-    unsigned lo, hi;
-    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "i"((int)LO));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "i"((int)HI));
-    return __hiloint2double((int)hi, (int)lo);
-}
-constexpr unsigned nvx_lo32(double v) { return (unsigned)__builtin_bit_cast(unsigned long long, v); }
-constexpr unsigned nvx_hi32(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32); }
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1, in order
 template <int I, int N, typename F>
 __device__ __forceinline__ void nvx_static_for(F &&f)

@@ -25,7 +25,7 @@
 #include "nvx_tables.h"
 #include "nvx_kernels.h"
 #include "nvx_device.h"
-#include "nvx_cascade_wave.h"          // NVX_TAP, NVX_F23_AHEAD
+#include "nvx_cascade_wave.h"          // NVX_F23_AHEAD
 
 #define F3_TILE_OUT 32                                  /* outputs per tile                              */
 #define F3_TILE_IN (10 * F3_TILE_OUT)                   /* new FIR2 outputs per tile                     */
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void nvx_fir3(nvx_fir3_args a)
         nvx_static_for<0, NVX_T3>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (i + NVX_F23_AHEAD < NVX_T3) { NVX_PIN_AFTER(acc); xs3[i + NVX_F23_AHEAD] = yb[2 * (79 - (i + NVX_F23_AHEAD))]; }
-            acc += NVX_TAP(NVX_H3, i) * xs3[i];
+            acc += NVX_H3[i] * xs3[i];
         });
         ((double *)(y3 + t * F3_TILE_OUT + o))[comp] = acc;
     }

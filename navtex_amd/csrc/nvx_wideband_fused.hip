@@ -1,8 +1,8 @@
 // nvx_wideband_fused.hip -- the wideband receive path as ONE kernel (gfx950): a 2.016 MS/s stream is read from HBM once,
 // channelised into eight 252 kS/s sub-bands IN LDS, and every sub-band runs the two-chain cascade (FIR1 -> mixers ->
 // FIR2 -> FIR3) from there: 16 NAVTEX carriers per input stream, no sub-band round trip through HBM.
-// (nvx_channelise.hip + nvx_fir_cascade<false, 2> do the same through a [8 x n_wide][samples] buffer: 3 x the bytes.
-// That path stays behind NVX_WB_FUSED=0 for A/B runs and as the stand-alone channeliser of header section G.)
+// (The stand-alone channeliser of header section G, nvx_channelise.hip, followed by nvx_fir_cascade<false, 2> does the same
+// through a [8 x n_wide][samples] buffer in HBM: 3 x the bytes.  A wideband handle runs this kernel only.)
 //
 // No reference counterpart: the reference tunes ONE 252 kS/s slice (receiver/capt_sched.c:356-417); the cascade part is
 // the reference's arithmetic (nvx_cascade_wave.h), the channeliser is build-owned integer arithmetic (nvx_pfb.h).
@@ -252,9 +252,8 @@ extern "C" hipError_t nvx_launch_wideband_fused(const nvx_wideband_args *a, hipS
     nvx_wideband_args args = *a;
     static const int force = getenv("NVX_INDEPENDENT") ? atoi(getenv("NVX_INDEPENDENT")) : -1;
     args.independent = force >= 0 ? force : (a->n_wide < resident && a->n_frames > 1);
-    // ... and in thirds when even that leaves two thirds of the chip idle (one RSP capture replayed).  NVX_TAIL_SPLIT=0: whole frames.
-    static const int no_thirds = getenv("NVX_TAIL_SPLIT") && atoi(getenv("NVX_TAIL_SPLIT")) == 0;
-    args.thirds = args.independent && !no_thirds && 3 * units <= resident;
+    // ... and in thirds when even that leaves two thirds of the chip idle (one RSP capture replayed)
+    args.thirds = args.independent && 3 * units <= resident;
     const long long all_units = units * (args.thirds ? 3 : 1);
     const unsigned grid = (unsigned)(all_units < resident ? all_units : resident);
     hipLaunchKernelGGL(nvx_wideband_fused, dim3(grid), dim3(512), 0, s, args);

@@ -57,16 +57,28 @@ def test_oracle_replay_is_one_pipe_fed_the_same_samples_again(nv, oracle):
         assert got[2 * k] == p.bits(0) and got[2 * k + 1] == p.bits(1) and len(p.bits(0)) > 100, k
 
 
-def test_traffic_record_is_per_shape_and_front_end():
+def test_traffic_record_is_per_shape_front_end_and_kernel_source(monkeypatch):
+    """roofline.traffic is a static PMC record: quoted only for the (streams, frames, stage-0 order) it was taken on AND only
+    while the kernel's sources are the ones it was taken on (an entry carries their hash); otherwise null, with the reason."""
     import bench
-    b1, src1 = bench.traffic_record(4096, 12, 1)
-    assert b1 and 1.0 <= b1 / (4 * 4096 * 12 * 645120) < 1.03 and "static" in src1
+    rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+    assert {(e["streams"], e["frames"], e.get("stage0_order", 1)) for e in rec["entries"]} >= {(4096, 12, 1), (4096, 12, 3)}
+    for e in rec["entries"]:
+        shape = (e["streams"], e["frames"], e.get("stage0_order", 1))
+        assert e["bytes_per_launch"] == int(e["fetch_size_kb"] * 1024 * 2 + e["write_size_kb"] * 1024)
+        assert 1.0 <= e["bytes_per_launch"] / (4 * e["streams"] * e["frames"] * 645120) < 1.03
+        # taken on these sources: quoted ...
+        monkeypatch.setattr(bench, "kernel_source_hash", lambda h=e.get("kernel_source_sha256_16"): h)
+        b, src = bench.traffic_record(*shape)
+        assert b == e["bytes_per_launch"] and "static" in src
+        # ... on others: not
+        monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0123456789abcdef")
+        b, why = bench.traffic_record(*shape)
+        assert b is None and why.startswith("null") and "kernel sources" in why
+    monkeypatch.undo()
     none, why = bench.traffic_record(64, 12, 1)
     assert none is None and why.startswith("null") and "(64, 12, 1)" in why
-    rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
-    for e in rec["entries"]:                                    # every entry is what bench.py would return for its shape
-        assert bench.traffic_record(e["streams"], e["frames"], e.get("stage0_order", 1))[0] == e["bytes_per_launch"]
-        assert e["bytes_per_launch"] == int(e["fetch_size_kb"] * 1024 * 2 + e["write_size_kb"] * 1024)
+    assert len(bench.kernel_source_hash()) == 16
 
 
 def test_a_leg_that_raises_fails_the_run_with_status_4(tmp_path, capsys):
