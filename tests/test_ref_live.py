@@ -128,6 +128,54 @@ def test_capt_sched_dsp_symbols_resolve_from_the_library(nv):
         assert sym not in undefined
 
 
+def test_capt_scheds_own_declarations_and_calls_link_against_the_library(nv, tmp_path):
+    """The literal form of the link claim that CAN be made here.  receiver/capt_sched.c itself cannot be compiled in this
+    image (it includes the vendor's sdrplay_api.h; a hand-written stand-in header would turn the proof into a guess about
+    that header -- not allowed, and not evidence).  But the part of the file that touches the DSP can be used AS IT IS:
+    at test time this reads capt_sched.c's own three declaration lines (:17-19), its own three call statements (:511,
+    :554, :612) and message_store.h's add_message prototype (:7), puts them -- verbatim, nothing of ours in between but
+    `short sample_buffer[2]; int index = 0;` and the braces -- into a C file under tmp_path, compiles it with gcc as the
+    reference's build would (C, not C++: the declarations are K&R-style `()`), and links it against -lnavtex_amd and
+    nothing else.  The link succeeds; in the program the three symbols are undefined and resolve from libnavtex_amd.so
+    (DT_NEEDED), and its own add_message overrides the library's weak one."""
+    import re
+    import subprocess
+    from pathlib import Path
+    ref = Path("/root/reference/receiver")
+    if not (ref / "capt_sched.c").exists():
+        pytest.skip("reference sources not present")
+    text = (ref / "capt_sched.c").read_text(errors="replace").splitlines()
+    decls = [l for l in text[:40] if re.match(r"^\s*void\s+(init_fir_filter1|sample_in_1|init_fir2_wrapper)\s*\(", l)]
+    assert len(decls) == 3
+    calls = {}
+    for i, l in enumerate(text):
+        m = re.match(r"^\s*(init_fir_filter1|sample_in_1|init_fir2_wrapper)\s*\(.*\)\s*;\s*$", l)
+        if m and i > 40:
+            calls.setdefault(m.group(1), l)
+    assert set(calls) == {"init_fir_filter1", "sample_in_1", "init_fir2_wrapper"}
+    assert "sample_buffer[index]" in calls["sample_in_1"] and "(double)" in calls["sample_in_1"]
+    proto = [l for l in (ref / "message_store.h").read_text().splitlines() if re.match(r"^\s*int\s+add_message\s*\(", l)]
+    assert len(proto) == 1
+    src = tmp_path / "drop_in.c"
+    src.write_text("\n".join(
+        ["/* generated by tests/test_ref_live.py at test time from the reference's own lines; never committed */"] + decls + proto +
+        ["int add_message(char *bbbb,char *message, int freq) { (void)bbbb; (void)message; return freq; }",
+         "short sample_buffer[2]; int index = 0;", "int main(void) {", calls["init_fir_filter1"], calls["init_fir2_wrapper"], calls["sample_in_1"], "return 0; }"]) + "\n")
+    libdir = Path(nv.lib._name).parent
+    exe = tmp_path / "drop_in"
+    r = subprocess.run(["gcc", "-O2", "-Wall", str(src), "-o", str(exe), f"-L{libdir}", "-lnavtex_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    syms = subprocess.run(["nm", "-D", str(exe)], capture_output=True, text=True, check=True).stdout
+    for name in ("init_fir_filter1", "sample_in_1", "init_fir2_wrapper"):
+        assert re.search(rf"^\s+U {name}$", syms, flags=re.M), f"{name} is not an undefined dynamic symbol of the program"
+    assert re.search(r"^[0-9a-f]+ T add_message$", syms, flags=re.M)          # the program's own sink, exported: it overrides the library's weak one
+    needed = subprocess.run(["readelf", "-d", str(exe)], capture_output=True, text=True, check=True).stdout
+    assert "libnavtex_amd.so" in needed
+    # (it is not RUN here: this container has no GPU, and the library has no CPU path -- tests/test_gpu_boundary.py runs
+    # the look-alike program tests/harness/capt_loop.c, which keeps capt_sched.c's ring, callback and consumer loop)
+
+
 def test_replay_is_what_the_reference_does_with_the_same_frames_again(nv, oracle):
     """bench.py's parity gate AFTER its timed region rests on nvxo_replay: the same frames pushed `loops` times into one
     pipe, state carried from repeat to repeat.  The reference carries that state in its statics (receiver/fir1cpp.C:51-60,
