@@ -35,9 +35,6 @@
 #include "nvx_cascade_wave.h"
 #include "nvx_pfb.h"
 
-#ifndef NVX_WB_PROBE
-#define NVX_WB_PROBE 0                   /* timing-only elimination probes (results are wrong): 1 = no barrier behind the channeliser, 2 = none in the pass loop, 3 = no channeliser arithmetic, 4 = no cascade pass */
-#endif
 #define WB_SPIN_LIMIT (1 << 22)
 #define WB_PASS_WORDS 2048
 
@@ -186,31 +183,21 @@ __device__ __forceinline__ void wideband_main(const nvx_wideband_args &a)
             *(u32x4 *)&L.raw[40 + 256 * wave + 4 * lane] = pf;
             src += WB_PASS_WORDS / 4;
             if (pass + 1 < n_pass) pf = __builtin_nontemporal_load(src);
-#if !(NVX_WB_PROBE >= 2)
             __syncthreads();                            // raw window complete; every wave is done with the last pass's windows
-#endif
             // ---- 2. channeliser: every wave 32 instants, a lane pair per instant (one component each); instant m's
             //         48-word window is raw[8m .. 8m+47]
             {
                 int y[8];
-#if NVX_WB_PROBE == 3
-                { const unsigned t = L.raw[8 * (32 * wave + (lane >> 1)) + 40]; for (int k = 0; k < 8; k++) y[k] = (int)(short)(t >> (16 * (lane & 1))) + k; }
-#else
                 nvx_pfb_instant_split(&L.raw[8 * (32 * wave + (lane >> 1))], lane & 1, y);
-#endif
 #pragma unroll
                 for (int k = 0; k < NVX_WB_SUBBANDS_K; k++)
                     ((double *)&L.sub[k].X[xslot])[lane & 1] = (double)y[k];            // capt_sched.c:511: (double) of each short
             }
-#if !(NVX_WB_PROBE >= 1)
             __syncthreads();                            // windows filled; raw window consumed
-#endif
             // ---- 3. the newest 40 raw samples are the halo of the next pass (wave 7 owns that end of the window: its
             //         own next store in step 1 follows this copy in its LDS queue); then the cascade pass
             if (wave == 7 && lane < 40) { const unsigned t = L.raw[WB_PASS_WORDS + lane]; NVX_WAVE_LDS_FENCE(); L.raw[lane] = t; }
-#if NVX_WB_PROBE != 4
             cw.compute_pass();
-#endif
         }
 
         // ------------------------------------------------------ state out (sc1 stores), publish
