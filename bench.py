@@ -562,8 +562,23 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
     ok_last = got == want and all(len(b[0]) > 0 and len(b[1]) > 0 for b in want)
     stale, failures, _ = p.integrity_stats()
     partial = p.stream_stats(0)[2]
+    # ... and the END of an input (nvx_finish): from reset, eight streams fed three frames and a ragged tail each (a different
+    # length per stream, none a multiple of anything), ended in ONE launch at their true lengths -- the bits of both chains
+    # are exactly the oracle's on the same samples: no padding decoded, nothing withheld (receiver/capt_sched.c:509-513 stops
+    # with its last sample)
+    p.reset()
+    n_tail, ok_tail, tails = min(8, n_streams), True, []
+    for s in range(n_tail):
+        n_s = min(n_per, 3 * nv.FRAME_RAW + 2240 * (9 + 31 * s) + 17 * s + 3)      # (the bit timing is primed after 582 samples at 900 S/s: two frames)
+        tails.append(n_s)
+        p.push(s, host[s, :n_s])
+    p.finish()
+    for s in range(n_tail):
+        ref = ob.Pipe(chain_mask=3, charlayer=False)
+        ref.push_raw(host[s, : tails[s] // 8 * 8])
+        ok_tail = ok_tail and p.bits(s, 0) == ref.bits(0) and p.bits(s, 1) == ref.bits(1) and len(ref.bits(0)) > 0
     p.close()
-    ok = ok_first and ok_last
+    ok = ok_first and ok_last and ok_tail
     n = passes * n_streams * n_per
     return {"what": f"HOST-FED: {n_streams} streams x 2.016 MS/s pushed from host memory by {n_thr} threads, {fpp} frames at a time (nvx_push_iq -> pinned staging -> "
                     f"hipMemcpyAsync -> kernels -> bits -> character layer), both chains of every stream decoded, {passes} passes over {n_fr} frames; PCIe-inclusive, never `value`",
@@ -573,6 +588,7 @@ def leg_push_path(nv, ob, buf, pitch, F, device, ncpu, n_streams=64, frames_per_
             "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
             "parity": ok, "parity_streams_checked": n_streams, "parity_chains_checked": 2 * n_streams,
             "parity_after_timed": ok_last, "parity_after_timed_passes": 1 + passes,
+            "end_of_stream_parity": ok_tail, "end_of_stream_lengths": tails,
             "parity_note": "both chains of every stream == oracle after the first pass (from reset) AND after the last (everything decoded over "
                            f"{1 + passes} passes over the same frames, state carried)"}
 

@@ -141,6 +141,48 @@ def test_tails_of_many_streams_in_one_launch_raw_rate_and_wideband(nv, oracle):
                     assert p.bits(8 * w + k, c) == ref.bits(c), f"wideband input {w} band {k} chain {c}"
 
 
+@pytest.mark.parametrize("raw", [False, True], ids=["252k", "raw"])
+def test_random_tails_of_many_streams_end_in_one_launch(nv, oracle, raw):
+    """48 streams of one handle, random chain masks, random lengths (one to three frames and a random tail, some tails empty,
+    some shorter than one 900 S/s sample), pushed in random order and chunk sizes with flushes in between; then nvx_finish:
+    whole frames first, then ONE launch that carries every tail at its own length.  Every chain of every stream == the
+    oracle on exactly the stream's samples."""
+    import signals
+    rate, frame, per_y3 = (nv.RATE_RAW, nv.FRAME_RAW, 2240) if raw else (nv.RATE_IN, nv.FRAME_IN, 280)
+    rng = np.random.default_rng(31 + int(raw))
+    S = 48
+    masks = [int(rng.choice([1, 2, 3])) for _ in range(S)]
+    lens = []
+    for s in range(S):
+        tail = 0 if s % 11 == 0 else (int(rng.integers(1, per_y3)) if s % 13 == 0 else int(rng.integers(per_y3, frame)))
+        lens.append(int(rng.integers(1, 4)) * frame + tail)
+    iqs = []
+    for s in range(S):
+        car = [dict(freq_hz=f, bits=nv.sitor_encode(signals.stream_text(300 + s), 6), bit_offset=(197 * (s + 1)) % (rate // 100) | 1, phase0=s * 424243, amplitude=5000)
+               for c, f in ((0, 14000), (1, -14000)) if (masks[s] >> c) & 1]
+        iqs.append(nv.synth_host(nv.make_stream(car, seed=300 + s, noise_amp=1200), rate, lens[s]))
+    with nv.Pipeline(n_streams=S, raw_rate=raw, chain_masks=masks, max_frames=2, push_mode=True, char_layer=False, stall_timeout_ms=-1) as p:
+        pos = [0] * S
+        live = list(range(S))
+        while live:
+            s = int(rng.choice(live))
+            m = int(min(lens[s] - pos[s], rng.integers(1, frame)))
+            p.push(s, iqs[s][pos[s]:pos[s] + m]); pos[s] += m
+            if pos[s] == lens[s]:
+                live.remove(s)
+            if rng.integers(0, 40) == 0:
+                p.flush()
+        launches_before = p.wait_stats()[2]
+        p.finish()
+        for s in range(S):
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
+            (ref.push_raw if raw else ref.push)(iqs[s][: lens[s] // 8 * 8] if raw else iqs[s])
+            for c in range(2):
+                want = ref.bits(c) if (masks[s] >> c) & 1 else ""
+                assert p.bits(s, c) == want, f"stream {s} chain {c} mask {masks[s]} length {lens[s]}"
+        assert p.integrity_stats()[:2] == (0, 0) and launches_before > 0
+
+
 def test_wav_file_path_config0(nv, tmp_path):
     """configs[0]/[1] plumbing: 2-channel 16-bit 252 kHz WAV -> nvx_decode_wav -> bits and messages, exactly the compiled
     reference's on the same samples (the file's last, partial frame runs at its true length); also a file of ragged length."""
