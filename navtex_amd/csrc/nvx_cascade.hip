@@ -174,7 +174,7 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // the independent-unit form, +2.9 % of a unit, identical results) and only
 // PUBLISHES behind its predecessor, so the state block and done[] still advance
 // in order.  1.4 % of the units at the headline size, 10 % with 252 kS/s input;
-// cascade 20.86 -> 20.30 ms and 74.4-78.4 -> 73.7 ms (DESIGN.md tuning log).
+// cascade 20.86 -> 20.30 ms and 74.4-78.4 -> 73.7 ms (profiles/TUNING.md).
 // NVX_DYNAMIC_PREROLL=0: such a unit waits, as in round 1.
 // Why: LDS limits residency to 11 waves per CU (2816), so 4096 equal-length
 // per-stream jobs would run as a VALU-saturated first round and a
@@ -185,7 +185,7 @@ __device__ __forceinline__ void load_pass(u32x4 (&pf)[RAW ? 8 : 1], const u32x4 
 // segment where it is used (s_load, per unit) and the pass loop has that many more scalar registers; by value every field
 // sits in a scalar register from the first instruction on.  Same results, different register allocation -- measured on
 // one box, interleaved: raw-rate kernel 20.28 / 20.39 ms by reference against 20.76 / 20.86 by value; the 252 kS/s kernel
-// showed nothing beyond its run-to-run spread, so its code stays as it was (DESIGN.md tuning log).
+// showed nothing beyond its run-to-run spread, so its code stays as it was (profiles/TUNING.md).
 // LIST: the launch names its streams (nvx_kernels.h, nvx_part: a push-mode handle whose streams have come apart in
 // time).  A kernel of its own, so that the launches of every stream -- the roofline configuration -- run exactly the
 // code they ran before lists existed (with the list test inside it the headline kernel was 0.8 % slower: 20.50 against

@@ -7,7 +7,7 @@
 // interleaved: 18.61 -> 17.72 ms, 18.9 -> 18.0 ms); here every lane computes an output and the work runs beside the
 // NEXT launch on the second stream, like the demodulator it feeds.  The single-wave 252 kS/s cascade (Variant A) gained
 // 2.4 % in the kernel and nothing in the step: its persistent grid fills every CU, nvx_fir3 beside it takes 42 ms
-// instead of 4.6, and the chain FIR3 -> demodulator then sets the step (profiles/r04/e0_*; DESIGN.md tuning log); it
+// instead of 4.6, and the chain FIR3 -> demodulator then sets the step (profiles/r04/e0_*; profiles/TUNING.md); it
 // keeps FIR3 inside.  So do the raw-rate kernels: HBM-bound, and 9 kS/s fp64 out and back would be + 3.6 % traffic.
 //
 // Arithmetic contract, unchanged: y3[k] = sum_{i=0..70} h3[i] * y2[10k + 9 - i], ONE lane per (output, component),

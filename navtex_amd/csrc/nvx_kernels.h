@@ -13,14 +13,14 @@
  * empty (6720 = 30 * 224 = 60 * 112, 960 = 6 * 160 = 12 * 80); only the mixer index does not
  * return to 0 (6720 mod 9 = 6).  Thirds for EVERY frame lose (round 1: 20.58 vs 20.39-20.53 ms; round 2, with the
  * dynamic pre-roll: 21.0 vs 20.6): a switch of unit costs more than its state traffic.  Thirds for the LAST frame of a
- * launch shorten the ragged end of the persistent grid from a frame to a third (nvx_cascade.hip, DESIGN.md tuning log). */
+ * launch shorten the ragged end of the persistent grid from a frame to a third (nvx_cascade.hip, profiles/TUNING.md). */
 #define NVX_THIRD_PASSES (NVX_PASSES_PER_FRAME / 3)
 #define NVX_THIRD_Y3 (NVX_Y3_PER_FRAME / 3)
 /* r4: the waves of the fused wideband kernel (nvx_wideband_fused) end at FIR2: their 9 kS/s outputs go to HBM and FIR3
  * (71 taps, /10, receiver/fir3cpp.C:22-60) is a kernel of its own (nvx_fir3.hip) in front of the demodulator, beside the
  * next launch.  Inside the wave FIR3 ran on half of the lanes; out of it the fused kernel is 4.8 % faster and so is the
  * step.  The single-wave cascade kernels keep FIR3 inside (252 kS/s input: 2.4 % in the kernel, nothing in the step;
- * raw-rate input: HBM-bound, the extra traffic would cost more) -- nvx_fir3.hip, DESIGN.md tuning log.
+ * raw-rate input: HBM-bound, the extra traffic would cost more) -- nvx_fir3.hip, profiles/TUNING.md.
  * y2 rows: one per ACTIVE chain (y2_row[slot], -1 = none), NVX_Y2_PREFIX entries in front of the launch's own outputs;
  * entries PREFIX-70 .. PREFIX-1 hold the last 70 outputs of the chain's previous launch (FIR3's history).  Two buffers:
  * a stream of parity p writes the outputs of its launch into [p]; nvx_fir3 reads [p] and leaves the tail in [p ^ 1]'s

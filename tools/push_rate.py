@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-fed (PCIe-inclusive) throughput of the push path: pinned staging ->
-hipMemcpy2DAsync -> kernels -> bits.  Reported in DESIGN.md; never bench.py's value."""
+hipMemcpy2DAsync -> kernels -> bits.  Reported in profiles/TUNING.md; never bench.py's value."""
 import sys, time
 from pathlib import Path
 import numpy as np
