@@ -220,11 +220,13 @@ def test_wideband_streams_advance_independently(nv, oracle):
         assert got == want and all(len(b) > 50 for b in want)
 
 
-def ragged_case(nv, oracle, seed):
+def ragged_case(nv, oracle, seed, tails=False):
     """Random handles (stream count, chain masks, input rate, stage-0 order, max_frames) fed in random order with random
     chunk sizes, streams going silent for a while (explicitly inactive, or simply not fed until another stream's staging
     fills), a reset-free flush in the middle: every list kernel (252 kS/s and raw rate, one and two chains, both stage-0
-    forms) meets partial launches, per-stream parities and per-stream sample counts.  Every chain == the oracle."""
+    forms) meets partial launches, per-stream parities and per-stream sample counts.  Every chain == the oracle.
+    tails: every stream's input also ends with a ragged tail of its own (some empty, some shorter than one 900 S/s sample)
+    and the handle is ended with nvx_finish instead of flushed: the bits are the oracle's on exactly those samples."""
     rng = np.random.default_rng(1000 + seed)
     raw = bool(rng.integers(0, 2))
     order = int(rng.choice([1, 3])) if raw else 1
@@ -242,19 +244,29 @@ def ragged_case(nv, oracle, seed):
                 carriers.append(dict(freq_hz=f, bits=nv.sitor_encode(f"ZCZC R{chr(65 + s)}{seed}{c}\nRAGGED {s}\nNNNN\n", 10),
                                      bit_offset=(h % (rate // 100)) | 1, phase0=signals.mix32(h), amplitude=6000))
         iqs.append(nv.synth_host(nv.make_stream(carriers, seed=seed * 100 + s, noise_amp=1200), rate, F * frame))
+    total = [F * frame] * S
+    if tails:                                                   # (a generator of its own: the cases above keep their draws)
+        trng = np.random.default_rng(77000 + seed)
+        per_y3 = 2240 if raw else 280
+        for s in range(S):
+            k = int(trng.integers(0, 5))
+            t = 0 if k == 0 else (int(trng.integers(1, per_y3)) if k == 1 else int(trng.integers(per_y3, frame)))
+            total[s] += t
+            st = nv.make_stream([], seed=seed * 100 + s + 50, noise_amp=3000)
+            if t: iqs[s] = np.vstack([iqs[s], nv.synth_host(st, rate, t)])
     with nv.Pipeline(n_streams=S, raw_rate=raw, chain_masks=masks, max_frames=maxf, push_mode=True, char_layer=False, stage0_order=order) as p:
         pos = [0] * S
         asleep = {}                                             # stream -> pushes (of others) until it wakes
         flushed = False
-        while any(q < F * frame for q in pos):
+        while any(pos[s] < total[s] for s in range(S)):
             for s in list(asleep):
                 asleep[s] -= 1
                 if asleep[s] <= 0: del asleep[s]
-            live = [s for s in range(S) if pos[s] < F * frame and s not in asleep]
+            live = [s for s in range(S) if pos[s] < total[s] and s not in asleep]
             if not live:
                 asleep.clear(); continue
             s = int(rng.choice(live))
-            m = int(min(F * frame - pos[s], rng.integers(1, 2 * frame)))
+            m = int(min(total[s] - pos[s], rng.integers(1, 2 * frame)))
             p.push(s, iqs[s][pos[s]:pos[s] + m]); pos[s] += m
             r = rng.random()
             if r < 0.08 and len(asleep) < S - 1:                # a radio goes quiet: sometimes declared, sometimes just silent
@@ -263,26 +275,36 @@ def ragged_case(nv, oracle, seed):
                 if rng.random() < 0.5: p.set_active(z, False)
             elif r < 0.11 and not flushed:
                 p.flush(); flushed = True
-        p.flush()
+        if tails: p.finish()
+        else: p.flush()
         partial = p.stream_stats(0)[2]
         stale = p.integrity_stats()[0]
         for s in range(S):
             ref = oracle.Pipe(chain_mask=masks[s], charlayer=False)
             if raw:
-                ref.set_stage0(order); ref.push_raw(iqs[s])
+                ref.set_stage0(order); ref.push_raw(iqs[s][: total[s] // 8 * 8])
             else:
                 ref.push(iqs[s])
             for c in range(2):
                 want = ref.bits(c) if (masks[s] >> c) & 1 else ""
                 assert p.bits(s, c) == want, f"seed {seed}: stream {s} chain {c} (raw {raw}, order {order}, masks {masks}, max_frames {maxf})"
             assert p.stream_stats(s)[1] == F
-    return dict(seed=seed, raw=raw, order=order, streams=S, frames=F, max_frames=maxf, two_chain_kernel=3 in masks, partial_launches=partial, stale_repaired=stale)
+    return dict(seed=seed, raw=raw, order=order, streams=S, frames=F, max_frames=maxf, two_chain_kernel=3 in masks, partial_launches=partial, stale_repaired=stale,
+                tails=[t - F * frame for t in total] if tails else None)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_randomized_ragged_streams(nv, oracle, seed):
     info = ragged_case(nv, oracle, seed)
     assert info["partial_launches"] > 0, info               # every case really had launches of only some streams
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_randomized_ragged_streams_with_ragged_ends(nv, oracle, seed):
+    """The same random handles with every stream's input ending at a place of its own, ended by nvx_finish: streams that
+    have come apart in time (per-stream parities and sample counts) AND end raggedly, every list kernel form."""
+    info = ragged_case(nv, oracle, seed, tails=True)
+    assert info["partial_launches"] > 0 and any(info["tails"]), info
 
 
 def test_ragged_cases_cover_every_list_kernel(nv, oracle):
