@@ -296,6 +296,7 @@ extern "C" int nvx_stream_set_active(nvx_handle *h, int stream, int active)
     if (!h->cfg.push_mode) { nvx_set_error("nvx_stream_set_active: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::unique_lock<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->ended[stream]) active = 0;                    // an ended stream (nvx_finish) delivers nothing more: nobody waits for it
     h->active[stream] = active ? 1 : 0;
     // the others may have been waiting for exactly this stream; and when the LAST active stream goes silent, whole frames
     // that were waiting for company go out now rather than when a radio comes back
