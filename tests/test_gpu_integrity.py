@@ -3,9 +3,11 @@
 The reference keeps its filter histories in statics (receiver/fir1cpp.C:51-60, receiver/fir2cpp.C:74-83,
 receiver/fir3cpp.h:90-95); here they travel from work unit to work unit through a state block in HBM, inside a launch by
 a fence-free, per-instruction-coherent protocol that the hardware guide calls measured rather than guaranteed.  So every
-block carries a word over its contents and its position, and these tests show that the word really covers everything
-(any flipped bit, any swapped pair of entries, a block of the wrong position), that a stale hand-over is caught,
-repaired bit-exactly and counted, and that the shipped build never sees one."""
+block carries a word over its contents and its position, and these tests show what the word is for: any single flipped
+bit of a carried word, a block of the wrong position, stream or launch, and the swapped pairs tried below fail (it is a
+stale / torn block detector, not a permutation check: two words whose slot and lane rotations add up to the same total
+could be swapped unnoticed, nvx_cascade_wave.h); a stale hand-over is caught, repaired bit-exactly and counted; the
+shipped build never sees one; and a launch that fails poisons its handle until nvx_reset."""
 import json
 import os
 import subprocess
