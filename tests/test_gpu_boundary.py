@@ -202,9 +202,10 @@ def test_wav_file_path_config0(nv, tmp_path):
 
 
 def test_stream_callback_shape(nv):
-    """nvx_StreamACallback: planar xi/xq, jittered numSamples, cbContext = handle."""
+    """nvx_StreamACallback: planar xi/xq, jittered numSamples, cbContext = handle; the input as it is, ended by nvx_finish:
+    bits and messages exactly the compiled reference's."""
     rec = GOLD["iq"]["offset_490"]
-    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    iq = cases.make_iq(nv, rec["spec"])
     xi, xq = np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])
     rng = np.random.default_rng(9)
     with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=2, push_mode=True) as p:
@@ -215,8 +216,8 @@ def test_stream_callback_shape(nv):
             nv.lib.nvx_StreamACallback(a.ctypes.data, b.ctypes.data, None, m, 0, p._h)
             a[:] = 0; b[:] = 0
             pos += m
-        p.flush()
-        assert p.bits(0, 1)[: len(rec["bits490"])] == rec["bits490"]
+        p.finish()
+        assert p.bits(0, 1) == rec["bits490"] and p.bits(0, 0) == rec["bits518"]
         assert sorted([f, b, m] for (_s, f, b, m) in p.messages) == sorted(rec["messages"])
 
 
@@ -600,11 +601,11 @@ def test_messages_land_in_the_sqlite_database(nv, tmp_path):
     reference's web server reads (nvx_store_on_message as the handle's sink)."""
     import sqlite3
     rec = GOLD["iq"]["two_carrier"]
-    iq = pad_to_frame(nv, cases.make_iq(nv, rec["spec"]))
+    iq = cases.make_iq(nv, rec["spec"])
     db = str(tmp_path / "Navtex.db")
     with nv.Store(db) as st, nv.Pipeline(n_streams=1, raw_rate=False, max_frames=4, push_mode=True, store=st) as p:
         p.push(0, iq)
-        p.flush()
+        p.finish()
         assert st.stats() == (len(rec["messages"]), 0) and p.messages == []
     con = sqlite3.connect(db)
     got = con.execute("select freq,bbbb,message,age from messages order by id").fetchall()
