@@ -639,6 +639,29 @@ def test_capture_debug_recording_reproduces_the_input(nv, tmp_path):
         assert p.bits(0, 0) == live and len(live) > 100
 
 
+def test_a_capture_that_ends_is_finished_exactly(nv):
+    """The live path's end: a capture ring fed the `ragged_length` golden input (1 s + 1237 samples) in callback-sized
+    pieces, nvx_capture_stop (drains the ring, flushes whole frames; the partial frame stays staged), then nvx_finish:
+    bits and messages are exactly the compiled reference's -- and the same for a recording of two carriers."""
+    for name in ("ragged_length", "two_carrier"):
+        rec = GOLD["iq"][name]
+        iq = cases.make_iq(nv, rec["spec"])
+        xi, xq = np.ascontiguousarray(iq[:, 0]), np.ascontiguousarray(iq[:, 1])
+        rng = np.random.default_rng(3)
+        with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=2, push_mode=True) as p:
+            cap = nv.Capture(p, 0, 8.0)
+            pos = 0
+            while pos < xi.size:
+                m = int(min(xi.size - pos, rng.integers(200, 3000)))
+                cap.feed(xi[pos:pos + m], xq[pos:pos + m]); pos += m
+            cap.stop()
+            early = p.bits(0, 0)                         # whole frames only so far: a proper prefix of the reference's bits
+            assert rec["bits518"].startswith(early) and len(early) < len(rec["bits518"])
+            p.finish()
+            assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"], name
+            assert got_messages(p) == gold_messages(rec)
+
+
 def test_two_receivers_two_capture_rings_one_handle(nv, oracle):
     """Two SDRs on one GPU handle: each has its own ring and vendor thread (jittered callbacks,
     different signals); a launch happens whenever both streams have a whole frame staged."""
