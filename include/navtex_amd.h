@@ -344,7 +344,8 @@ NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
 #define NVX_STATE_BLOCK_BYTES 4352
 NVX_API int    nvx_debug_cascade_state(nvx_handle *h, int stream, void *buf, size_t bytes, int write);
 /* debug tap: copy the 900 S/s FIR-cascade output of the LAST launch for one
- * (stream, chain) to host: out[2*k], out[2*k+1] = I,Q; returns sample count  */
+ * (stream, chain) to host: out[2*k], out[2*k+1] = I,Q; returns sample count
+ * (for a stream ended by nvx_finish: the samples its real input produced)     */
 NVX_API size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out, size_t cap_pairs);
 /* debug tap: discriminator output (delta-phi) of the last launch             */
 NVX_API size_t nvx_debug_dphi(nvx_handle *h, int stream, int chain, double *out, size_t cap);

@@ -717,6 +717,10 @@ extern "C" size_t nvx_debug_y3(nvx_handle *h, int stream, int chain, double *out
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     size_t n = std::min(cap_pairs, (size_t)h->last_n3);
+    // a stream whose input has ended (nvx_finish): only the samples its real input produced (the rest of the frame was
+    // computed from the zeros behind its last sample and is not part of anything)
+    const int in = h->cfg.wideband ? stream / NVX_WB_SUBBANDS : stream;
+    if (h->ended[in]) n = std::min(n, (size_t)(h->g0s[in] % NVX_FRAME_Y3));
     if (hipMemcpy(out, h->d_y3[(h->launched + 1) & 1] + (size_t)(2 * stream + chain) * h->y3_cap, n * sizeof(double2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }

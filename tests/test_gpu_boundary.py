@@ -85,13 +85,18 @@ def test_every_kind_of_tail_matches_the_oracle(nv, oracle, cut):
     st, _ = signals.stream_params(nv, 5, nv.RATE_IN)
     n = 3 * nv.FRAME_IN + cut
     iq = nv.synth_host(st, nv.RATE_IN, n)
-    ref = oracle.Pipe(chain_mask=3, charlayer=False)
+    ref = oracle.Pipe(chain_mask=3, charlayer=False, tap_y3=4 * nv.FRAME_Y3)
     ref.push(iq)
     with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=2, push_mode=True, char_layer=False) as p:
         p.push(0, iq)
         p.finish()
         assert p.bits(0, 0) == ref.bits(0) and p.bits(0, 1) == ref.bits(1)
         assert len(ref.bits(0)) >= 28
+        if cut >= 280:                               # the tail's own launch: exactly the 900 S/s samples the real input produced, bit for bit
+            for c in (0, 1):
+                want = np.ascontiguousarray(ref.y3(c)[3 * nv.FRAME_Y3:])
+                got = p.debug_y3(0, c)
+                assert want.shape[0] == cut // 280 and got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64))
 
 
 def test_tails_of_many_streams_in_one_launch_raw_rate_and_wideband(nv, oracle):
