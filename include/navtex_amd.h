@@ -224,6 +224,11 @@ typedef void (*nvx_trace_fn)(void *user, const char *text);
 NVX_API int  nvx_set_trace(nvx_handle *h, nvx_trace_fn fn, void *user);
 /* zero all carried DSP state (FIR histories, demodulator, character layer)  */
 NVX_API int  nvx_reset(nvx_handle *h);
+/* ... the same for ONE stream, while the others keep everything they carry: an ended stream (nvx_finish /
+ * nvx_decode_wav) starts a new input -- the next file, the next capture.  Waits for the handle's launched work and
+ * delivers its bits and messages first; the stream's bit counters restart at 0.  A handle whose launch failed
+ * (NVX_ERR_STATE everywhere) needs nvx_reset.                                                                    */
+NVX_API int  nvx_stream_reset(nvx_handle *h, int stream);
 
 /* ---- host-input path (pinned staging + hipMemcpyAsync) -------------------
  * Interleaved I,Q int16 (the layout of the reference's sample_buffer,
@@ -263,7 +268,7 @@ NVX_API int nvx_flush(nvx_handle *h);
  * the demodulator stops at the stream's last real 900 S/s sample (floor(n / 280) at 252 kS/s input, floor(n / 2240) at
  * 2.016 MS/s); no padding is decoded, no bit is withheld: the bits of a stream are then exactly the reference's on the
  * same samples, whatever the length.  A stream that held a partial frame is ENDED afterwards (its filters have run
- * past its last sample): nvx_push_* and launches that name it return NVX_ERR_STATE until nvx_reset.  Streams that
+ * past its last sample): nvx_push_* and launches that name it return NVX_ERR_STATE until nvx_reset / nvx_stream_reset.  Streams that
  * ended on a frame boundary are not affected.  nvx_stream_finish: the same for one stream (the whole frames of the
  * others are launched as by nvx_flush).                                                                            */
 NVX_API int nvx_finish(nvx_handle *h);
@@ -443,7 +448,7 @@ NVX_API const char *nvx_wav_err(void);                                  /* wav.h
 /* File harness the reference lacks: open -> loop wav_read ->
  * the capt_sched.c:509-513 loop, on the GPU, ended by nvx_stream_finish: the
  * bits are the reference's on the same file, whatever its length; the stream is
- * ended afterwards (nvx_reset starts a new one).  Returns the number of frames
+ * ended afterwards (nvx_stream_reset / nvx_reset start a new one).  Returns the number of frames
  * (the last one may be partial) or a negative error.                          */
 NVX_API int nvx_decode_wav(nvx_handle *h, int stream, const char *filename);
 

@@ -296,6 +296,14 @@ class Pipeline(HandleStats):
         self._bits.clear()
         self.messages.clear()
 
+    def stream_reset(self, stream: int) -> None:
+        """One stream starts anew (nvx_stream_reset): its filters, demodulator, character layers and bit counters; the other
+        streams keep everything they carry.  What an ended stream (finish / decode_wav) needs before its next input."""
+        N.check(lib.nvx_stream_reset(self._h, stream), "nvx_stream_reset")
+        per = 8 if self.wideband else 1
+        for key in [k for k in self._bits if per * stream <= k[0] < per * (stream + 1)]:
+            del self._bits[key]
+
     def enable_debug(self, on: bool = True) -> None:
         N.check(lib.nvx_enable_debug(self._h, int(on)), "nvx_enable_debug")
 

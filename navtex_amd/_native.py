@@ -71,7 +71,7 @@ def _load() -> C.CDLL:
         "nvx_cascade_integrity_stats": (i, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i]), "nvx_capture_pause": (None, [vp, i]),
         "nvx_capture_stats": (None, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "nvx_config_default": (None, [C.POINTER(Config)]),
-        "nvx_create": (i, [C.POINTER(Config), C.POINTER(vp)]), "nvx_destroy": (None, [vp]), "nvx_reset": (i, [vp]),
+        "nvx_create": (i, [C.POINTER(Config), C.POINTER(vp)]), "nvx_destroy": (None, [vp]), "nvx_reset": (i, [vp]), "nvx_stream_reset": (i, [vp, i]),
         "nvx_push_iq": (i, [vp, i, vp, sz]), "nvx_push_planar": (i, [vp, i, vp, vp, sz]), "nvx_flush": (i, [vp]),
         "nvx_finish": (i, [vp]), "nvx_stream_finish": (i, [vp, i]),
         "nvx_poll_bits": (sz, [vp, i, i, C.c_char_p, sz]),

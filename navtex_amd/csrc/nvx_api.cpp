@@ -175,6 +175,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->y2_pitch = (size_t)NVX_Y2_PREFIX + (size_t)cfg->max_frames * NVX_Y2_PER_FRAME;
         CR_TRY(hipMalloc(&h->d_y2row, (size_t)h->n_slots * sizeof(int)));
         CR_TRY(hipMemcpy(h->d_y2row, rows.data(), (size_t)h->n_slots * sizeof(int), hipMemcpyHostToDevice));
+        h->y2row = rows;
         for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_y2[i], (size_t)h->y2_rows * h->y2_pitch * sizeof(double2)));
     }
     for (int i = 0; i < 2; i++) CR_TRY(hipMalloc(&h->d_dd[i], (size_t)NVX_DEMOD_DOUBLES * h->n_slots * sizeof(double)));
@@ -270,6 +271,53 @@ extern "C" int nvx_reset(nvx_handle *h)
         // (every copy out of the staging sets has finished: the streams were synchronised above)
         for (int i = 0; i < 2; i++) std::fill(h->set_launch[i].begin(), h->set_launch[i].end(), (uint64_t)0);
     }
+    return NVX_OK;
+}
+
+// One stream starts anew (header: nvx_stream_reset): what nvx_reset does, for the rows of ONE input stream -- the cascade
+// state blocks, the demodulator state, FIR3's history and the channeliser halo of a wideband handle, the character layers,
+// the bit history, the staging -- while the other streams keep everything they carry.  The handle's work is taken in
+// first (the stream's rows must be out of every kernel's reach); afterwards the streams are on different clocks, so
+// launches carry participant lists until they meet again.
+extern "C" int nvx_stream_reset(nvx_handle *h, int stream)
+{
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_reset: bad stream"); return NVX_ERR_ARG; }
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);                      // a failed launch taints every stream: nvx_reset
+    StagingQuiesce quiet(h, lk);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    { int rc = nvx_collect_locked(h); if (rc != NVX_OK) return rc; }   // bits and messages of everything launched so far are delivered
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream2));
+    const int per = h->cfg.wideband ? NVX_WB_SUBBANDS : 1;             // decoded streams of this input stream
+    const int d0 = per * stream, slot0 = 2 * d0, n_sl = 2 * per;
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMemsetAsync(h->d_cstate[i] + (size_t)d0 * NVX_CASCADE_STATE_BYTES, 0, (size_t)per * NVX_CASCADE_STATE_BYTES, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_dd[i] + (size_t)slot0 * NVX_DEMOD_DOUBLES, 0, (size_t)n_sl * NVX_DEMOD_DOUBLES * sizeof(double), h->stream));
+        if (h->d_whist[i]) HIP_TRY(hipMemsetAsync(h->d_whist[i] + (size_t)stream * 40, 0, 40 * 4, h->stream));
+        for (int k = 0; k < n_sl && h->d_y2[i]; k++)
+            if (h->y2row[slot0 + k] >= 0)
+                HIP_TRY(hipMemsetAsync(h->d_y2[i] + (size_t)h->y2row[slot0 + k] * h->y2_pitch, 0, (size_t)NVX_Y2_PREFIX * sizeof(double2), h->stream));
+    }
+    // ints: all zero except prev_offset = -1 (decoder.C:30) and the bit-FSM phase = -1 (waiting), as nvx_reset
+    std::vector<int> zero(n_sl, 0), minus(n_sl, -1);
+    for (int f = 0; f < NVX_DEMOD_INTS; f++) {
+        const int *src = (f == NVX_DI_PREV_OFFSET || f == NVX_DI_PHASE) ? minus.data() : zero.data();
+        HIP_TRY(hipMemcpyAsync(h->d_di + (size_t)f * h->n_slots + slot0, src, (size_t)n_sl * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n_sl; k++) {
+        Slot &s = h->slots[slot0 + k];
+        s.bits.clear(); s.base = 0; s.polled = 0;
+        if (s.sitor) nvx_sitor_reset(s.sitor);
+    }
+    h->g0s[stream] = 0; h->ended[stream] = 0;
+    if (!h->fill.empty()) { h->fill[stream] = 0; h->active[stream] = 1; h->last_push_ns[stream] = nvx_now_ns(); }
+    if (ArrivalClock *ac = h->arrival[stream]) { std::lock_guard<std::mutex> al(ac->mu); ac->base = UINT64_MAX; }
+    bool together = true;
+    for (int s = 1; s < h->n_in && together; s++) together = h->parity[s] == h->parity[0] && h->g0s[s] == h->g0s[0];
+    h->diverged = !together;
     return NVX_OK;
 }
 

@@ -129,6 +129,7 @@ struct nvx_handle {
     // active chain, two buffers by stream parity; the row table
     double2 *d_y2[2] = { nullptr, nullptr };
     int *d_y2row = nullptr;
+    std::vector<int> y2row;                    // host copy of the row table: row of slot i, or -1
     size_t y2_pitch = 0; int y2_rows = 0;
     double *d_dd[2] = { nullptr, nullptr };   // demodulator state blocks: a chain reads [its stream's parity], writes the other
     double *d_dphi = nullptr; int *d_di = nullptr;

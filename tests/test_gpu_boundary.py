@@ -206,6 +206,39 @@ def test_wav_file_path_config0(nv, tmp_path):
             p.decode_wav(path)
 
 
+def test_one_stream_starts_anew_while_the_others_carry_on(nv, oracle, tmp_path):
+    """nvx_stream_reset: stream 0 of a two-stream handle decodes one WAV file after another (each ended exactly by
+    nvx_decode_wav, then reset for the next) while stream 1 is fed a long signal in pieces in between and never notices:
+    every file's bits and messages are the compiled reference's, stream 1's bits the oracle's over its whole input.
+    An ended stream refuses input until it is reset; the reset restarts its bit counters."""
+    import signals
+    files = ["ragged_length", "offset_490", "two_carrier", "ragged_length"]
+    st, _ = signals.stream_params(nv, 91, nv.RATE_IN)
+    n1 = 9 * nv.FRAME_IN + 12345
+    iq1 = nv.synth_host(st, nv.RATE_IN, n1)
+    ref1 = oracle.Pipe(chain_mask=3, charlayer=False)
+    ref1.push(iq1)
+    with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=3, push_mode=True, stall_timeout_ms=-1) as p:
+        pos = 0
+        for k, name in enumerate(files):
+            rec = GOLD["iq"][name]
+            path = str(tmp_path / f"{k}_{name}.wav")
+            nv.wav_write(path, cases.make_iq(nv, rec["spec"]), nv.RATE_IN)
+            step = n1 // len(files) + 1
+            p.push(1, iq1[pos:pos + step]); pos += step          # the other receiver keeps running
+            p.messages.clear()
+            p.decode_wav(path, stream=0)
+            assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"], (k, name)
+            assert sorted([f, b, m] for (s_, f, b, m) in p.messages if s_ == 0) == sorted(rec["messages"]), (k, name)
+            with pytest.raises(nv.NvxError):                     # ended: nothing more goes in ...
+                p.push(0, np.zeros((8, 2), dtype=np.int16))
+            p.stream_reset(0)                                    # ... until it starts anew
+            assert p.bit_count(0, 0) == 0 and p.bits(0, 0) == ""
+        p.finish()
+        assert p.bits(1, 0) == ref1.bits(0) and p.bits(1, 1) == ref1.bits(1) and len(ref1.bits(0)) > 250
+        assert p.integrity_stats()[:2] == (0, 0)
+
+
 def test_stream_callback_shape(nv):
     """nvx_StreamACallback: planar xi/xq, jittered numSamples, cbContext = handle; the input as it is, ended by nvx_finish:
     bits and messages exactly the compiled reference's."""
