@@ -235,7 +235,8 @@ def test_one_stream_starts_anew_while_the_others_carry_on(nv, oracle, tmp_path):
             p.stream_reset(0)                                    # ... until it starts anew
             assert p.bit_count(0, 0) == 0 and p.bits(0, 0) == ""
         p.finish()
-        assert p.bits(1, 0) == ref1.bits(0) and p.bits(1, 1) == ref1.bits(1) and len(ref1.bits(0)) > 250
+        assert len(ref1.bits(0)) > 200
+        assert p.bits(1, 0) == ref1.bits(0) and p.bits(1, 1) == ref1.bits(1)
         assert p.integrity_stats()[:2] == (0, 0)
 
 
