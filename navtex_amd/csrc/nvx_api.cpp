@@ -339,7 +339,7 @@ int nvx_launch_locked(nvx_handle *h, const void *d_iq, size_t pitch, size_t firs
     const int n_named = part ? n_part : h->n_in;
     for (int i = 0; i < n_named; i++) {
         const int s = part ? part[i] : i;
-        if (h->ended[s]) { nvx_set_error("stream %d has ended (nvx_finish): nvx_reset starts a new one", s); return NVX_ERR_STATE; }
+        if (h->ended[s]) { nvx_set_error("stream %d has ended (nvx_finish): nvx_stream_reset or nvx_reset starts a new one", s); return NVX_ERR_STATE; }
         if (tail_n3 && (tail_n3[i] < 1 || tail_n3[i] >= n_frames * NVX_FRAME_Y3)) { nvx_set_error("launch list: %d samples at 900 S/s in the tail of stream %d", tail_n3[i], s); return NVX_ERR_ARG; }
     }
     Result &r = h->res[h->launched % RESULT_SLOTS];

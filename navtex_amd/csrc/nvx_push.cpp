@@ -112,7 +112,7 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::unique_lock<std::mutex> lk(h->mu);
     if (h->poisoned) return nvx_poisoned_error(h);
-    if (h->ended[stream]) { nvx_set_error("nvx_push: stream %d has ended (nvx_finish); nvx_reset starts a new one", stream); return NVX_ERR_STATE; }
+    if (h->ended[stream]) { nvx_set_error("nvx_push: stream %d has ended (nvx_finish); nvx_stream_reset or nvx_reset starts a new one", stream); return NVX_ERR_STATE; }
     HIP_TRY(hipSetDevice(h->cfg.device));
     // a stream has ONE pusher at a time, for the whole call (the lock is released while this one waits for a launch or
     // copies a large chunk: a second pusher of the same stream must not interleave its chunks with this one's)
