@@ -51,6 +51,23 @@ def test_full_path_random_signal(nv, oracle, seed):
     assert sorted(got) == sorted(tuple(m) for m in ob.parse_messages(full["messages"]))
 
 
+@pytest.mark.parametrize("cut", [0, 1, 279, 280, 281, 2519, 2520, 9 * 280 + 5, 17 * 280, 40000, 80639])
+def test_the_end_of_an_input_is_where_the_reference_stops(nv, oracle, cut):
+    """What the GPU's end-of-stream tests (tests/test_gpu_boundary.py::test_every_kind_of_tail_matches_the_oracle) compare
+    with is pinned here to the COMPILED REFERENCE: the same signal cut at the same places (three frames and a tail of
+    nothing, less than one 900 S/s sample, exactly one, whole and ragged bit periods, almost a frame) -- the reference's
+    loop (receiver/capt_sched.c:509-513) hands its objects exactly these samples and stops; the oracle's bits on both
+    chains are the reference's, bit for bit, at every cut."""
+    import signals
+    st, _ = signals.stream_params(nv, 5, nv.RATE_IN)
+    iq = nv.synth_host(st, nv.RATE_IN, 3 * nv.FRAME_IN + cut)
+    bits = ob.run_ref("bits", iq.tobytes())
+    p = oracle.Pipe(chain_mask=3, charlayer=False)
+    p.push(iq)
+    assert p.bits(0) == bits["bits518"].decode() and p.bits(1) == bits["bits490"].decode()
+    assert len(p.bits(0)) >= 28
+
+
 @pytest.mark.parametrize("seed", [31, 32, 33, 34])
 def test_character_layer_random_bits_and_flips(nv, oracle, seed):
     """Random garbage and randomly damaged traffic: messages and full trace, reference vs both implementations."""
