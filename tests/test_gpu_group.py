@@ -108,6 +108,35 @@ def test_group_host_input_and_errors(nv, oracle):
         nv.Group([0, 0, 0], n_streams=2)                       # fewer streams than members
 
 
+def test_group_finish_ends_every_members_streams_exactly(nv, oracle):
+    """nvx_group_finish: five streams over two members, every stream's input ending at a place of its own (one on a frame
+    boundary); pushes by global stream id, one finish for the whole group: every chain == the oracle on exactly its
+    samples; the ended streams refuse more input, the one that ended on a frame boundary does not."""
+    import signals
+    S = 5
+    masks = [3, 1, 2, 3, 1]
+    tails = [12345, 0, 279, 80639, 40000]
+    iqs = []
+    for s in range(S):
+        car = [dict(freq_hz=f, bits=nv.sitor_encode(signals.stream_text(700 + s), 8), bit_offset=(311 * (s + 1)) | 1, phase0=s * 7919, amplitude=5000)
+               for c, f in ((0, 14000), (1, -14000)) if (masks[s] >> c) & 1]
+        iqs.append(nv.synth_host(nv.make_stream(car, seed=700 + s, noise_amp=1000), nv.RATE_IN, 3 * nv.FRAME_IN + tails[s]))
+    with nv.Group([0, 0], n_streams=S, raw_rate=False, chain_masks=masks, max_frames=2, push_mode=True, char_layer=False) as g:
+        for s in range(S):
+            for pos in range(0, iqs[s].shape[0], 50000):
+                g.push(s, iqs[s][pos:pos + 50000])
+        g.finish()
+        for s in range(S):
+            ref = oracle.Pipe(chain_mask=masks[s], charlayer=False); ref.push(iqs[s])
+            for c in range(2):
+                assert g.bits(s, c) == (ref.bits(c) if (masks[s] >> c) & 1 else ""), (s, c)
+            if tails[s]:
+                with pytest.raises(nv.NvxError):
+                    g.push(s, iqs[s][:16])
+            else:
+                g.push(s, iqs[s][:16])
+
+
 def test_member_threads_bind_to_the_device_numa_node(nv):
     """nvx_bind_thread_to_device: never widens the affinity mask, never fails on a box without NUMA information."""
     import os, threading
