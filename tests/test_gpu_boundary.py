@@ -188,6 +188,23 @@ def test_random_tails_of_many_streams_end_in_one_launch(nv, oracle, raw):
         assert p.integrity_stats()[:2] == (0, 0) and launches_before > 0
 
 
+def test_empty_inputs(nv, tmp_path):
+    """Nothing in, nothing out, no error: a finish on a fresh handle, zero-length pushes, an empty WAV file (the golden
+    `empty` case of the WAV boundary) -- and the handle is as good as new afterwards (no stream is ended by it)."""
+    rec = GOLD["iq"]["ragged_length"]
+    iq = cases.make_iq(nv, rec["spec"])
+    path = str(tmp_path / "empty.wav")
+    nv.wav_write(path, np.zeros((0, 2), dtype=np.int16), nv.RATE_IN)
+    with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=2, push_mode=True) as p:
+        p.finish()
+        p.push(0, np.zeros((0, 2), dtype=np.int16)); p.push_planar(1, np.zeros(0, dtype=np.int16), np.zeros(0, dtype=np.int16))
+        p.flush(); p.finish()
+        assert p.decode_wav(path, stream=1) == 0
+        assert p.bits(0, 0) == "" and p.bits(1, 1) == "" and p.messages == [] and p.stream_stats(0)[1] == 0
+        p.push(0, iq); p.finish(0)
+        assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
+
+
 def test_wav_file_path_config0(nv, tmp_path):
     """configs[0]/[1] plumbing: 2-channel 16-bit 252 kHz WAV -> nvx_decode_wav -> bits and messages, exactly the compiled
     reference's on the same samples (the file's last, partial frame runs at its true length); also a file of ragged length."""
