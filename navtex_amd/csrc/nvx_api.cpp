@@ -213,6 +213,7 @@ extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
         h->active.assign(h->n_in, 1);
         h->writing.assign(h->n_in, 0);
         h->pushing.assign(h->n_in, 0);
+        h->closing.assign(h->n_in, 0);
         h->last_push_ns.assign(h->n_in, nvx_now_ns());
         h->stall_ns.assign(h->n_in, cfg->stall_timeout_ms < 0 ? 0 : (int64_t)(cfg->stall_timeout_ms ? cfg->stall_timeout_ms : 2000) * 1000000);
     }
@@ -228,6 +229,7 @@ extern "C" int nvx_reset(nvx_handle *h)
 {
     if (!h) return NVX_ERR_ARG;
     std::unique_lock<std::mutex> lk(h->mu);
+    StreamClose closing(h, lk, 0, h->n_in);              // push calls in progress end first; later ones start on the fresh streams
     StagingQuiesce quiet(h, lk);                         // no push is copying into the staging sets while they are emptied
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));   // launches on a caller's stream included
@@ -284,6 +286,8 @@ extern "C" int nvx_stream_reset(nvx_handle *h, int stream)
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_stream_reset: bad stream"); return NVX_ERR_ARG; }
     std::unique_lock<std::mutex> lk(h->mu);
     if (h->poisoned) return nvx_poisoned_error(h);                      // a failed launch taints every stream: nvx_reset
+    StreamClose closing(h, lk, stream, stream + 1);                     // a push call in progress on this stream ends first (nvx_handle.h)
+    if (h->poisoned) return nvx_poisoned_error(h);                      // (the wait released the lock)
     StagingQuiesce quiet(h, lk);
     HIP_TRY(hipSetDevice(h->cfg.device));
     { int rc = nvx_collect_locked(h); if (rc != NVX_OK) return rc; }   // bits and messages of everything launched so far are delivered

@@ -193,6 +193,7 @@ struct nvx_handle {
     // quiesce, waits on wr_cv for writers == 0 (no new copy starts meanwhile) and lowers it again.
     std::vector<uint8_t> writing;
     std::vector<uint8_t> pushing;              // stream s has a push call in progress (one pusher per stream, for the whole call)
+    std::vector<uint8_t> closing;              // how many finish / reset calls are ending or restarting stream s right now (StreamClose below)
     std::vector<int64_t> last_push_ns;         // when stream s last delivered samples (nvx_now_ns; create / reset count as a delivery)
     std::vector<int64_t> stall_ns;             // how long the others' launches wait for stream s after that (0 = for ever): cfg.stall_timeout_ms,
                                                // or the timeout of the capture ring attached to the stream (nvx_capture_set_stall_timeout)
@@ -212,6 +213,24 @@ struct StagingQuiesce {
         h->wr_cv.wait(lk, [&] { return h->writers == 0; });
     }
     ~StagingQuiesce() { h->quiesce--; h->wr_cv.notify_all(); }
+};
+
+// Scope in which streams [first, last) of a push-mode handle are ENDED or RESTARTED (nvx_finish, nvx_stream_finish,
+// nvx_stream_reset, nvx_reset).  A push call is atomic against these: the calls already in progress on the streams run
+// to their end first (each is finite: a pusher that needs a launch makes it itself), and a call that arrives meanwhile
+// waits at its entry until the scope is left -- then it finds the stream ended (NVX_ERR_STATE, nothing staged) or
+// fresh.  Without it a pusher that had released the lock inside its loop went on staging samples into a stream that
+// nvx_finish had ended under it, and that stream then vetoed every launch of the handle.
+// Raised with the handle locked and BEFORE a StagingQuiesce (a pusher in its loop waits for quiesce == 0).
+struct StreamClose {
+    nvx_handle *h; int first, last;
+    StreamClose(nvx_handle *h_, std::unique_lock<std::mutex> &lk, int first_, int last_) : h(h_), first(first_), last(last_)
+    {
+        if (h->pushing.empty()) { first = last = 0; return; }           // not a push-mode handle: nobody pushes
+        for (int s = first; s < last; s++) h->closing[s]++;
+        h->wr_cv.wait(lk, [&] { for (int s = first; s < last; s++) if (h->pushing[s]) return false; return true; });
+    }
+    ~StreamClose() { for (int s = first; s < last; s++) h->closing[s]--; if (first != last) h->wr_cv.notify_all(); }
 };
 
 // launch cascade + demodulator over n_frames frames of [n_streams][pitch] packed IQ (handle locked)

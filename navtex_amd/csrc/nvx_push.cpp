@@ -21,12 +21,12 @@ static bool lockstep_ready(const nvx_handle *h)
 {
     bool any = false;
     if (h->cfg.eager_launch) {                       // cfg.eager_launch: whoever has a whole frame goes now (a handful of free-running radios)
-        for (int s = 0; s < h->n_in; s++) if (h->fill[s] >= h->frame_in) return true;
+        for (int s = 0; s < h->n_in; s++) if (!h->ended[s] && h->fill[s] >= h->frame_in) return true;
         return false;
     }
     const int64_t now = nvx_now_ns();
     for (int s = 0; s < h->n_in; s++) {
-        if (!h->active[s]) continue;
+        if (!h->active[s] || h->ended[s]) continue;      // (an ended stream holds nothing and is waited for by nobody)
         if (h->fill[s] < h->frame_in) {
             if (h->stall_ns[s] > 0 && now - h->last_push_ns[s] > h->stall_ns[s]) continue;       // gone quiet: not waited for
             return false;
@@ -45,7 +45,7 @@ static int submit_locked(nvx_handle *h)
     int frames = h->cfg.max_frames;
     for (int s = 0; s < h->n_in; s++) {
         const int f = n_whole_frames(h, s);
-        if (f < 1) continue;
+        if (f < 1 || h->ended[s]) continue;          // (an ended stream never vetoes the others' launch: nvx_launch_locked refuses a list that names one)
         part.push_back(s);
         frames = std::min(frames, f);
     }
@@ -111,12 +111,17 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
     if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_push: bad stream"); return NVX_ERR_ARG; }
     if (!h->cfg.push_mode) { nvx_set_error("nvx_push: handle was not created with push_mode"); return NVX_ERR_STATE; }
     std::unique_lock<std::mutex> lk(h->mu);
-    if (h->poisoned) return nvx_poisoned_error(h);
-    if (h->ended[stream]) { nvx_set_error("nvx_push: stream %d has ended (nvx_finish); nvx_stream_reset or nvx_reset starts a new one", stream); return NVX_ERR_STATE; }
     HIP_TRY(hipSetDevice(h->cfg.device));
     // a stream has ONE pusher at a time, for the whole call (the lock is released while this one waits for a launch or
-    // copies a large chunk: a second pusher of the same stream must not interleave its chunks with this one's)
-    h->wr_cv.wait(lk, [&] { return !h->pushing[stream]; });
+    // copies a large chunk: a second pusher of the same stream must not interleave its chunks with this one's); and a
+    // call that arrives while the stream is being ended or restarted (StreamClose, nvx_handle.h) waits for the outcome
+    h->wr_cv.wait(lk, [&] { return !h->pushing[stream] && !h->closing[stream]; });
+    auto refused = [&]() -> int {                        // looked at whenever the lock has been away
+        if (h->poisoned) return nvx_poisoned_error(h);
+        if (h->ended[stream]) { nvx_set_error("nvx_push: stream %d has ended (nvx_finish); nvx_stream_reset or nvx_reset starts a new one", stream); return NVX_ERR_STATE; }
+        return NVX_OK;
+    };
+    { int rc = refused(); if (rc != NVX_OK) return rc; }
     h->pushing[stream] = 1;
     struct Release {
         nvx_handle *h; int stream;
@@ -131,7 +136,13 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
         return still() ? submit_locked(h) : NVX_OK;
     };
     while (done < n) {
-        if (h->quiesce) h->wr_cv.wait(lk, [&] { return h->quiesce == 0; });     // somebody is rearranging the staging sets
+        if (h->quiesce) {                            // somebody is rearranging the staging sets
+            h->wr_cv.wait(lk, [&] { return h->quiesce == 0; });
+            // (a StreamClose waits for this call to end before it ends or restarts the stream, so `ended` cannot have
+            // come up under a push in progress; a launch that failed meanwhile has poisoned the handle)
+            int rc = refused();
+            if (rc != NVX_OK) { if (accepted) *accepted = done; return rc; }
+        }
         size_t room = h->stage_cap - h->fill[stream];
         if (room == 0) {
             // this stream is max_frames + 1 frames ahead of a launch: go with the streams that have a frame
@@ -225,13 +236,20 @@ static int finish_locked(nvx_handle *h, std::unique_lock<std::mutex> &lk, int st
     if (h->poisoned) return nvx_poisoned_error(h);
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->cfg.push_mode) {
+        // A push call is atomic against the end of its stream: the calls in progress on the streams that are ending run
+        // to their end first, calls that arrive meanwhile wait and then find the stream ended (nvx_handle.h: StreamClose).
+        StreamClose closing(h, lk, stream < 0 ? 0 : stream, stream < 0 ? h->n_in : stream + 1);
+        if (h->poisoned) return nvx_poisoned_error(h);
         StagingQuiesce quiet(h, lk);
         int rc = submit_whole_frames_locked(h);
         if (rc != NVX_OK) return rc;
         const size_t per_y3 = (h->cfg.raw_rate || h->cfg.wideband) ? (size_t)(280 * NVX_DECIM0) : (size_t)280;     // input samples per 900 S/s sample
         std::vector<int> part, n3;
         for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? h->n_in : stream + 1); s++) {
-            if (h->ended[s] || h->fill[s] == 0) continue;                 // (a stream that ends on a frame boundary simply goes on later)
+            if (h->ended[s]) continue;
+            // a stream that ends on a frame boundary is not ended by this (its state is a valid continuation: a later push goes
+            // on bit-exactly, and makes it active again) -- but it delivers nothing for now, so nobody waits for it
+            if (h->fill[s] == 0) { h->active[s] = 0; continue; }
             const int t = (int)(h->fill[s] / per_y3);
             if (t > 0) { part.push_back(s); n3.push_back(t); }
             else { h->fill[s] = 0; h->ended[s] = 1; h->active[s] = 0; }  // too short for one more 900 S/s sample: nothing to decode
@@ -286,6 +304,14 @@ extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
     // last sample, receiver/capt_sched.c:509-513)
     rc = nvx_stream_finish(h, stream);
     if (rc != NVX_OK) return rc;
+    // A FILE has an end whatever its length: a file of whole frames leaves nothing for nvx_stream_finish to run, but the
+    // stream is ended all the same, so that the next file on this stream needs its nvx_stream_reset as after any other
+    // length (and is never silently decoded as the continuation of this one).  An empty file ends nothing.
+    if (total > 0) {
+        std::unique_lock<std::mutex> lk(h->mu);
+        StreamClose closing(h, lk, stream, stream + 1);
+        if (!h->ended[stream] && h->fill[stream] == 0) { h->ended[stream] = 1; h->active[stream] = 0; }
+    }
     return (int)((total + h->frame_in - 1) / h->frame_in);
 }
 

@@ -75,7 +75,10 @@ def test_push_path_is_clean_under_tsan(tmp_path):
     """ThreadSanitizer over the host-input path (nvx_push.cpp): six pusher threads (callback-sized and replay-sized pushes,
     the big ones copying into the staging WITHOUT the handle's lock), a slow stream, a stream declared silent, a thread
     flushing; HIP and the launch are stand-ins that record what reached the "device".  No race; every stream's samples
-    arrive exactly once and in order; partial launches really happened (tests/harness/tsan_push.cpp)."""
+    arrive exactly once and in order; partial launches really happened.  Then streams are ended (nvx_stream_finish, nvx_finish)
+    under pushers that are in the middle of calls, in both launch modes: every call is accepted whole or refused whole, what
+    reaches the "device" is exactly what was accepted, nothing is staged behind a stream's end and no launch ever names an
+    ended stream -- the other streams keep launching (tests/harness/tsan_push.cpp)."""
     exe = tmp_path / "tsan_push"
     csrc = ROOT / "navtex_amd" / "csrc"
     subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
