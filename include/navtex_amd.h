@@ -30,11 +30,17 @@ enum {
     NVX_ERR_HIP     = -3,   /* a HIP runtime call failed; see nvx_last_error()   */
     NVX_ERR_NOMEM   = -4,
     NVX_ERR_STATE   = -5,   /* call not valid in the handle's current mode       */
-    NVX_ERR_IO      = -6,   /* file errors of the WAV path                       */
-    NVX_ERR_FULL    = -7    /* (no longer returned: the streams of a handle launch independently) */
+    NVX_ERR_IO      = -6    /* file errors of the WAV path                       */
+    /* (-7 was NVX_ERR_FULL of ABI 1, "staging full": never returned since the streams of a handle launch
+     * independently; the value stays unused so that no later code is mistaken for it)                    */
 };
 NVX_API const char *nvx_last_error(void);
+/* "navtex_amd <abi>.<minor> (gfx950)".  NVX_ABI_VERSION counts incompatible changes of this header (struct layouts,
+ * signatures): 2 = nvx_config begins with struct_size, nvx_capture_error lost its second parameter, NVX_ERR_FULL is
+ * gone.  nvx_abi_version() returns the library's; a caller built against another value must be rebuilt.          */
+#define NVX_ABI_VERSION 2
 NVX_API const char *nvx_version(void);
+NVX_API int nvx_abi_version(void);
 
 /* ------------------------------------------------------------- rate algebra */
 #define NVX_RATE_RAW      2016000   /* receiver/capt_sched.c:31-34 H_SAMPLE_RATE          */
@@ -56,13 +62,48 @@ NVX_API const char *nvx_version(void);
  *    Replaces receiver/fir1cpp.o fir2cpp.o fir3cpp.o decoder.o nav_b_sm.o
  *    nav_sched.o at link time: an unmodified receiver/capt_sched.c calls these
  *    three symbols (declarations capt_sched.c:17-19; calls :511, :554, :612).
- *    Same contract: no return value, process-global singleton, one caller
- *    thread.  Samples are buffered into frames and run on GPU 0; characters
- *    leave through add_message().
+ *    The contract as capt_sched.c uses it: no return value, process-global
+ *    singleton, one caller thread, each init called once before the first
+ *    sample, int16 values cast to double.  Samples are buffered into frames and
+ *    run on GPU 0; characters leave through add_message().  On the same samples
+ *    the bits and messages are the reference's.
+ *
+ *    Where this surface deliberately does NOT behave like the reference
+ *    (DESIGN.md section 4.4 has the table, tests/test_deviations.py the tests):
+ *    1. Re-initialisation.  The reference's init_fir_filter1() clears FIR1's
+ *       ring and counter only (receiver/fir1cpp.C:65-77); its init_fir2_wrapper()
+ *       clears the 518 chain's FIR2 ring and the mixer index both chains share
+ *       (receiver/fir2cpp.C:90-110) -- never the 490 chain's FIR2 statics, FIR3,
+ *       the decoders or the character layers.  Called once at start-up, as
+ *       capt_sched.c does (:552-555, :612), that is "everything zero".  Called
+ *       AGAIN in mid-stream the reference goes on with half its pipeline
+ *       cleared; this library cannot represent that state (a frame is the span
+ *       after which all decimation counters are at phase 0 together) and does
+ *       not try: here init_fir_filter1() always starts a NEW stream -- all
+ *       carried state zeroed, samples buffered but not yet decoded dropped --
+ *       and a repeated init_fir2_wrapper() changes nothing.
+ *    2. Input domain.  The reference filters any double; sample_in_1 here takes
+ *       int16 VALUES (what capt_sched.c:511 passes).  Anything else -- a
+ *       fraction, a value beyond the int16 range, a NaN -- is rounded to the
+ *       nearest int16 (ties to even, NaN to 0) and counted: nvx_shim_stats.
+ *       nvx_sample_to_int16 is that conversion (returns 1 when v was an int16
+ *       value already).
+ *    3. Long runs.  The reference's decoder counts samples in an `int`
+ *       (receiver/decoder.h:60, decoder.C:75,85) that passes INT_MAX after
+ *       2^31 samples at 900 S/s = 27.6 days; from then on its bit timing test
+ *       (bd_seq_nbr % 9 == offset) fails for every offset but 0 and it falls
+ *       nearly silent for the next 27.6 days.  The bit phase here is a function
+ *       of the sample's position; decoding simply goes on.
+ *    4. A sample behind nvx_shim_finish starts a new stream (the reference
+ *       never ends one).
  * ========================================================================== */
 NVX_API void init_fir_filter1(void);                       /* receiver/fir1cpp.h:2  */
 NVX_API void sample_in_1(double sample_I, double sample_Q);/* receiver/fir1cpp.h:3  */
 NVX_API void init_fir2_wrapper(void);                      /* receiver/nav_sched.h:1 */
+NVX_API int  nvx_sample_to_int16(double v, int16_t *out);
+/* sample_in_1 calls since the library was loaded, and how many of them carried a value outside the input domain
+ * (the first one also prints a line to stderr and sets nvx_last_error); either pointer may be NULL              */
+NVX_API int  nvx_shim_stats(uint64_t *samples, uint64_t *off_domain);
 
 /* Characters-out sink, receiver/message_store.h:7 (impl message_store.c:59-97).
  * The library only CALLS this symbol.  A weak default that prints the message
@@ -83,7 +124,7 @@ NVX_API int nvx_shim_flush(void);
 /* END of the input (a file replayed through sample_in_1, a capture that is over): nvx_shim_flush, then the last,
  * partial frame at its true length -- nvx_finish of section C on the singleton.  Afterwards the singleton has decoded
  * exactly the bits the reference's objects have decoded when capt_sched.c's loop (:509-513) has handed them the same
- * samples and stopped.  init_fir_filter1 starts a new stream.                                                        */
+ * samples and stopped.  The next sample (or init_fir_filter1) starts a new stream.                                   */
 NVX_API int nvx_shim_finish(void);
 /* Decode latency of this surface, per frame of 0.32 s: from the entry of the sample_in_1 call (or singleton stream
  * callback) that carried the frame's last sample to its bits being pollable and its messages delivered to
@@ -172,6 +213,10 @@ typedef struct nvx_handle nvx_handle;
 typedef void (*nvx_message_fn)(void *user, int stream, const char *bbbb, const char *message, int freq);
 
 typedef struct nvx_config {
+    uint32_t struct_size;     /* sizeof(nvx_config) of the header the CALLER was built with: set by      */
+                              /* nvx_config_default, checked by nvx_create / nvx_group_create -- a caller */
+                              /* built against another layout gets NVX_ERR_ARG instead of a struct read   */
+                              /* past its end.  First member, so that it sits inside every version.       */
     int      device;          /* HIP device ordinal                                        */
     int      n_streams;       /* independent IQ streams on this GPU                        */
     int      raw_rate;        /* 1: input at 2.016 MS/s, integer stage 0 (/8) on device;   */
@@ -345,6 +390,15 @@ NVX_API int   nvx_demod_tie_stats(nvx_handle *h, uint64_t *near_ties, uint64_t *
  * generated from (receiver/decoder.C:62-137, 202-249), on `periods` pseudo-random bit periods;
  * returns the number of differences (0 = pass).  Host only, no device needed.                  */
 NVX_API int   nvx_fsm_selftest(uint32_t seed, int periods);
+/* test / diagnostics hook: move a stream's sample clock FORWARD by `periods` x 163 296 samples at 900 S/s (567 frames =
+ * lcm of the frame, 288, and of the bit-timing filter's ring algebra, 9 x 567) without touching a sample of its state:
+ * every index the kernels derive from the clock is the same afterwards, so decoding goes on exactly as if nothing had
+ * happened -- unless some part of the path does not carry the clock in 64 bits.  tests/test_gpu_deviations.py uses it to
+ * put a stream just below 2^31 samples, where the reference's `int bd_seq_nbr` overflows after 27.6 days
+ * (receiver/decoder.h:60, decoder.C:75,85), and to walk it across.  Waits for the handle's launches; re-tags the seal of
+ * the stream's carried FIR state for its new position.  Not for wideband handles (NVX_ERR_STATE).                     */
+#define NVX_CLOCK_PERIOD 163296
+NVX_API int   nvx_debug_advance_clock(nvx_handle *h, int stream, uint64_t periods);
 /* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */
 NVX_API int   nvx_enable_debug(nvx_handle *h, int enabled);
 /* test / diagnostics hook: the carried FIR state block of one decoded stream -- the block the stream's NEXT launch will

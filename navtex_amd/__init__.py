@@ -319,6 +319,13 @@ class Pipeline(HandleStats):
         block = np.ascontiguousarray(block, dtype=np.uint64)
         N.check(lib.nvx_debug_cascade_state(self._h, stream, N.as_ptr(block), block.nbytes, 1), "nvx_debug_cascade_state")
 
+    CLOCK_PERIOD = 163296
+
+    def debug_advance_clock(self, stream: int, periods: int) -> None:
+        """Move the stream's 900 S/s sample clock forward by periods x CLOCK_PERIOD without touching its state
+        (nvx_debug_advance_clock): decoding must go on as if nothing had happened."""
+        N.check(lib.nvx_debug_advance_clock(self._h, stream, periods), "nvx_debug_advance_clock")
+
     def debug_y3(self, stream: int = 0, chain: int = 0) -> np.ndarray:
         out = np.empty((self.max_frames * FRAME_Y3, 2), dtype=np.float64)
         n = lib.nvx_debug_y3(self._h, stream, chain, N.as_ptr(out), out.shape[0])

@@ -14,7 +14,7 @@ import numpy as np
 # NAVTEX_AMD_LIB: load another build of the same library (A/B runs of kernel variants)
 _LIB_PATH = Path(os.environ.get("NAVTEX_AMD_LIB") or (Path(__file__).resolve().parent / "libnavtex_amd.so"))
 
-OK, ERR_ARG, ERR_NODEV, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_IO, ERR_FULL = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_ARG, ERR_NODEV, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_IO = 0, -1, -2, -3, -4, -5, -6
 RATE_RAW, RATE_IN = 2016000, 252000
 FRAME_BITS, FRAME_IN, FRAME_RAW, FRAME_Y3 = 32, 80640, 645120, 288
 CHAIN_518, CHAIN_490 = 1, 2
@@ -26,7 +26,7 @@ SITOR_TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 
 class Config(C.Structure):
     _fields_ = [
-        ("device", C.c_int), ("n_streams", C.c_int), ("raw_rate", C.c_int), ("chain_mask", C.c_uint32),
+        ("struct_size", C.c_uint32), ("device", C.c_int), ("n_streams", C.c_int), ("raw_rate", C.c_int), ("chain_mask", C.c_uint32),
         ("chain_masks", C.POINTER(C.c_uint8)), ("labels", C.POINTER(C.c_int)), ("max_frames", C.c_int),
         ("char_layer", C.c_int), ("on_message", MESSAGE_FN), ("user", C.c_void_p), ("push_mode", C.c_int),
         ("wideband", C.c_int),
@@ -57,7 +57,9 @@ def _load() -> C.CDLL:
     lib = C.CDLL(str(_LIB_PATH))
     vp, sz, i, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
     sig = {
-        "nvx_last_error": (C.c_char_p, []), "nvx_version": (C.c_char_p, []),
+        "nvx_last_error": (C.c_char_p, []), "nvx_version": (C.c_char_p, []), "nvx_abi_version": (i, []),
+        "nvx_sample_to_int16": (i, [C.c_double, C.POINTER(C.c_int16)]), "nvx_shim_stats": (i, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "nvx_debug_advance_clock": (i, [vp, i, C.c_uint64]),
         "init_fir_filter1": (None, []), "sample_in_1": (None, [C.c_double, C.c_double]), "init_fir2_wrapper": (None, []),
         "nvx_set_trace": (i, [vp, SITOR_TRACE_FN, vp]),
         "nvx_shim_latency": (i, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), i]),

@@ -23,7 +23,10 @@ int64_t nvx_now_ns()
 {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-extern "C" const char *nvx_version(void) { return "navtex_amd 0.1 (gfx950)"; }
+#define NVX_STR2(x) #x
+#define NVX_STR(x) NVX_STR2(x)
+extern "C" const char *nvx_version(void) { return "navtex_amd " NVX_STR(NVX_ABI_VERSION) ".0 (gfx950)"; }
+extern "C" int nvx_abi_version(void) { return NVX_ABI_VERSION; }
 
 int nvx_select_device(int device)
 {
@@ -58,6 +61,7 @@ static void sitor_sink(void *user, const char *bbbb, const char *message, int fr
 extern "C" void nvx_config_default(nvx_config *c)
 {
     memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
     c->device = 0; c->n_streams = 1; c->raw_rate = 0;
     c->chain_mask = NVX_CHAIN_518 | NVX_CHAIN_490;
     c->max_frames = 1; c->char_layer = 1; c->push_mode = 0;
@@ -103,8 +107,15 @@ extern "C" void nvx_destroy(nvx_handle *h) { free_handle(h); }
 
 extern "C" int nvx_create(const nvx_config *cfg, nvx_handle **out)
 {
-    if (!cfg || !out || cfg->n_streams < 1 || cfg->max_frames < 1) { nvx_set_error("nvx_create: bad config"); return NVX_ERR_ARG; }
+    if (!cfg || !out) { nvx_set_error("nvx_create: null argument"); return NVX_ERR_ARG; }
     *out = nullptr;
+    // (the first member of every layout: nothing else of the caller's struct is read before this has passed)
+    if (cfg->struct_size != sizeof(nvx_config)) {
+        nvx_set_error("nvx_create: nvx_config.struct_size is %u, this library's nvx_config has %zu bytes (ABI %d): the caller was built against "
+                      "another navtex_amd.h, or did not start from nvx_config_default", cfg->struct_size, sizeof(nvx_config), NVX_ABI_VERSION);
+        return NVX_ERR_ARG;
+    }
+    if (cfg->n_streams < 1 || cfg->max_frames < 1) { nvx_set_error("nvx_create: bad config"); return NVX_ERR_ARG; }
     if (cfg->stage0_order != 0 && cfg->stage0_order != 1 && cfg->stage0_order != 3) { nvx_set_error("nvx_create: stage0_order %d (1 or 3)", cfg->stage0_order); return NVX_ERR_ARG; }
     if (cfg->stage0_order == 3 && !(cfg->raw_rate && !cfg->wideband)) { nvx_set_error("nvx_create: stage0_order 3 needs raw_rate input (a wideband handle has its channeliser, 252 kS/s input no stage 0)"); return NVX_ERR_ARG; }
     if (!cfg->push_mode && (cfg->eager_launch || cfg->stall_timeout_ms)) { nvx_set_error("nvx_create: eager_launch / stall_timeout_ms belong to push_mode handles"); return NVX_ERR_ARG; }
@@ -759,6 +770,51 @@ extern "C" int nvx_debug_cascade_state(nvx_handle *h, int stream, void *buf, siz
     uint8_t *blk = h->d_cstate[h->parity[in]] + (size_t)stream * NVX_CASCADE_STATE_BYTES;
     if (write) HIP_TRY(hipMemcpy(blk, buf, bytes, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemcpy(buf, blk, bytes, hipMemcpyDeviceToHost));
+    return NVX_OK;
+}
+
+// host copy of seal_tag (nvx_cascade_wave.h): the tag a state block's seal is mixed with.  The kernels judge what this
+// writes (tests/test_gpu_deviations.py): a disagreement is a failed launch, not a silent one.
+static unsigned long long seal_tag_host(int stream, unsigned third)
+{
+    unsigned long long t = ((unsigned long long)(unsigned)stream << 32) | third;
+    t *= 0x9E3779B97F4A7C15ull; t ^= t >> 29; t *= 0xBF58476D1CE4E5B9ull; t ^= t >> 32;
+    return t;
+}
+
+// header: nvx_debug_advance_clock.  Everything the kernels derive from a stream's sample clock g is periodic in
+// NVX_CLOCK_PERIOD = lcm(288, 9 * 567): the frame phase (g mod 288), the bit-timing filter's ring position and class
+// (g mod 5103; nvx_demod.hip), the priming thresholds (g >= 8 / 574 / 582: once passed, passed) -- except the position tag
+// in the seal of the carried FIR state (g / 96), which is re-written here for the block the stream's next launch reads.
+static_assert(NVX_CLOCK_PERIOD % NVX_FRAME_Y3 == 0 && NVX_CLOCK_PERIOD % (9 * 567) == 0, "the clock's period");
+extern "C" int nvx_debug_advance_clock(nvx_handle *h, int stream, uint64_t periods)
+{
+    if (!h || stream < 0 || stream >= h->n_in) { nvx_set_error("nvx_debug_advance_clock: bad stream"); return NVX_ERR_ARG; }
+    if (h->cfg.wideband) { nvx_set_error("nvx_debug_advance_clock: not for wideband handles"); return NVX_ERR_STATE; }
+    std::unique_lock<std::mutex> lk(h->mu);
+    if (h->poisoned) return nvx_poisoned_error(h);
+    if (h->ended[stream]) { nvx_set_error("nvx_debug_advance_clock: stream %d has ended", stream); return NVX_ERR_STATE; }
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    { int rc = nvx_collect_locked(h); if (rc != NVX_OK) return rc; }
+    if (h->launch_done_valid) HIP_TRY(hipEventSynchronize(h->launch_done));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream2));
+    const unsigned long long g_old = h->g0s[stream];
+    if (periods > (~0ull - g_old) / (unsigned long long)NVX_CLOCK_PERIOD) { nvx_set_error("nvx_debug_advance_clock: the clock would pass 2^64"); return NVX_ERR_ARG; }
+    const unsigned long long g_new = g_old + periods * (unsigned long long)NVX_CLOCK_PERIOD;
+    const unsigned third_old = (unsigned)(g_old / (NVX_FRAME_Y3 / 3)), third_new = (unsigned)(g_new / (NVX_FRAME_Y3 / 3));
+    unsigned long long seal[2];
+    uint8_t *entry = h->d_cstate[h->parity[stream]] + (size_t)stream * NVX_CASCADE_STATE_BYTES + (size_t)NVX_STATE_SEAL * 16;
+    HIP_TRY(hipMemcpy(seal, entry, sizeof seal, hipMemcpyDeviceToHost));
+    // (position 0: nothing was ever stored, the block is nvx_reset's zeros and the kernels do not look at its seal; zeros
+    // fold to 0, so their seal at the new position is the tag alone)
+    seal[0] = (third_old ? seal[0] ^ seal_tag_host(stream, third_old) : 0ull) ^ seal_tag_host(stream, third_new);
+    seal[1] = ((unsigned long long)(unsigned)stream << 32) | third_new;
+    HIP_TRY(hipMemcpy(entry, seal, sizeof seal, hipMemcpyHostToDevice));
+    h->g0s[stream] = g_new;
+    bool together = true;
+    for (int s = 1; s < h->n_in && together; s++) together = h->parity[s] == h->parity[0] && h->g0s[s] == h->g0s[0];
+    h->diverged = !together;
     return NVX_OK;
 }
 

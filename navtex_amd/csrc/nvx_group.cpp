@@ -132,11 +132,16 @@ extern "C" void nvx_group_destroy(nvx_group *g)
 
 extern "C" int nvx_group_create(const int *devices, int n_members, const nvx_config *cfg, nvx_group **out)
 {
-    if (!devices || !cfg || !out || n_members < 1 || cfg->n_streams < n_members) {
+    if (!devices || !cfg || !out) { nvx_set_error("nvx_group_create: null argument"); return NVX_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(nvx_config)) {          // (as nvx_create: checked before anything else of the struct is read)
+        nvx_set_error("nvx_group_create: nvx_config.struct_size is %u, this library's nvx_config has %zu bytes (ABI %d)", cfg->struct_size, sizeof(nvx_config), NVX_ABI_VERSION);
+        return NVX_ERR_ARG;
+    }
+    if (n_members < 1 || cfg->n_streams < n_members) {
         nvx_set_error("nvx_group_create: bad argument (need at least one stream per member)");
         return NVX_ERR_ARG;
     }
-    *out = nullptr;
     nvx_group *g = new nvx_group();
     g->cfg = *cfg; g->total = cfg->n_streams;
     // streams addressed by the caller: wideband inputs or plain streams; masks / labels are per DECODED stream

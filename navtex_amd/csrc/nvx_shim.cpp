@@ -32,6 +32,8 @@ static size_t g_shim_n = 0;
 // carried a frame's LAST sample was entered -> its bits pollable and its messages at add_message (nvx_shim_latency).
 static ArrivalClock g_shim_clock;
 static uint64_t g_shim_samples = 0;              // samples taken since init_fir_filter1
+static bool g_shim_finished = false;             // nvx_shim_finish has ended the input: the next sample starts a new stream
+static std::atomic<uint64_t> g_shim_total{ 0 }, g_shim_off_domain{ 0 };   // sample_in_1 calls since the library was loaded / outside its input domain
 
 static void shim_fatal(const char *what)
 {
@@ -110,28 +112,68 @@ static void shim_drain(void)
     shim_wake_keeper();
 }
 
-extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
+// A NEW stream on the singleton: everything the path carries is zeroed, what was buffered but not yet decoded is dropped.
+// (g_shim_mu held.)
+static void shim_new_stream(void)
 {
-    std::lock_guard<std::mutex> lk(g_shim_mu);
     shim_require();
     g_shim_n = 0;
     if (nvx_reset(g_shim) != NVX_OK) shim_fatal("reset failed");
     g_shim_samples = 0;                          // (the reset ended the clock's bookkeeping: frame 0 starts here again)
     { std::lock_guard<std::mutex> ck(g_shim_clock.mu); g_shim_clock.base = 0; g_shim_clock.stamped = 0; }
+    g_shim_finished = false;
 }
 
+// DEVIATION from the reference (header section A): the reference's init_fir_filter1 clears FIR1's
+// ring and counter and nothing else (receiver/fir1cpp.C:65-77).  capt_sched.c calls it once, before the first sample
+// (:552-555), where "FIR1 cleared" and "everything cleared" are the same thing; called again in mid-stream the reference
+// would go on with FIR2, FIR3, both decoders and both character layers as they were -- a state the frame algebra here has
+// no word for (a frame is the span after which every decimation counter is back at phase 0 TOGETHER).  Here every call
+// starts a new stream.
+extern "C" void init_fir_filter1(void)           // receiver/fir1cpp.C:65-77
+{
+    std::lock_guard<std::mutex> lk(g_shim_mu);
+    shim_new_stream();
+}
+
+// DEVIATION, the same way: the reference's second init_fir2_wrapper would clear the 518 chain's FIR2 and the mixer index
+// both chains share (receiver/fir2cpp.C:90-110) in mid-stream; here it wires nothing twice and changes nothing.
 extern "C" void init_fir2_wrapper(void)          // receiver/nav_sched.C:19-22
 {
     std::lock_guard<std::mutex> lk(g_shim_mu);
     shim_require();                              // the object graph already exists; nothing else to wire
 }
 
+// The input domain of sample_in_1.  The reference filters whatever double it is given; its only caller hands it
+// (double) of an int16 (receiver/capt_sched.c:511), and int16 is what the GPU path is built on.  A value outside that
+// domain -- not an integer, beyond +-32767 / -32768, not a number -- is brought to the nearest int16 (ties to even; NaN
+// to 0): defined behaviour, at most half an LSB (or the clipping) away from what the reference would have filtered,
+// and COUNTED (nvx_shim_stats) -- never the undefined (int16_t) cast of an out-of-range double this once was.
+extern "C" int nvx_sample_to_int16(double v, int16_t *out)
+{
+    int16_t r; int exact;
+    if (v != v) { r = 0; exact = 0; }
+    else if (v >= 32767.0) { r = 32767; exact = v == 32767.0; }
+    else if (v <= -32768.0) { r = -32768; exact = v == -32768.0; }
+    else { const double n = __builtin_rint(v); r = (int16_t)n; exact = n == v; }
+    if (out) *out = r;
+    return exact;
+}
+
 extern "C" void sample_in_1(double sample_I, double sample_Q)   // receiver/fir1cpp.C:80
 {
-    // capt_sched.c:511 passes (double) of int16 values; the cast back is exact
     if (!g_shim) { std::lock_guard<std::mutex> lk(g_shim_mu); shim_require(); }
-    g_shim_buf[2 * g_shim_n] = (int16_t)sample_I;
-    g_shim_buf[2 * g_shim_n + 1] = (int16_t)sample_Q;
+    // a sample behind nvx_shim_finish: the input that ended there cannot be continued (its filters ran past its last
+    // sample), so this is the first sample of a new stream -- as if init_fir_filter1 had been called in between
+    if (g_shim_finished) { std::lock_guard<std::mutex> lk(g_shim_mu); shim_new_stream(); }
+    // capt_sched.c:511 passes (double) of int16 values: the conversion back is exact for those (and checked: above)
+    const int ok = nvx_sample_to_int16(sample_I, &g_shim_buf[2 * g_shim_n]) & nvx_sample_to_int16(sample_Q, &g_shim_buf[2 * g_shim_n + 1]);
+    // (one caller thread, the reference's contract: plain increments of what nvx_shim_stats may read from another thread)
+    g_shim_total.store(g_shim_total.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed);
+    if (!ok && g_shim_off_domain.fetch_add(1, std::memory_order_relaxed) == 0) {
+        nvx_set_error("sample_in_1(%g, %g): not an int16 value (receiver/capt_sched.c:511 passes int16); rounded / clipped, counted in nvx_shim_stats", sample_I, sample_Q);
+        fprintf(stderr, "navtex_amd: %s\n", nvx_last_error());
+    }
     ++g_shim_n;
     // the sample that completes a frame goes to the pipeline at once (its launch should not wait for up to 4095 more
     // samples, 16 ms at the real rate), and the frame's arrival is stamped for the latency bookkeeping
@@ -160,7 +202,15 @@ extern "C" int nvx_shim_finish(void)
     std::lock_guard<std::mutex> lk(g_shim_mu);
     if (!g_shim) { nvx_set_error("shim not initialised"); return NVX_ERR_STATE; }
     shim_drain();
+    g_shim_finished = true;                      // whatever comes next is a new stream (sample_in_1, nvx_StreamACallback)
     return nvx_finish(g_shim);                   // the last, partial frame at its true length (capt_sched.c:509-513 stops with its last sample)
+}
+
+extern "C" int nvx_shim_stats(uint64_t *samples, uint64_t *off_domain)
+{
+    if (samples) *samples = g_shim_total.load();
+    if (off_domain) *off_domain = g_shim_off_domain.load();
+    return NVX_OK;
 }
 
 extern "C" size_t nvx_shim_bits(int chain, char *out, size_t cap)
@@ -177,7 +227,9 @@ extern "C" void nvx_StreamACallback(short *xi, short *xq, void *params, unsigned
     nvx_handle *h = (nvx_handle *)cbContext;
     if (!h || h == g_shim) {                     // the singleton, named or not: its samples count for nvx_shim_latency
         const int64_t t_enter = nvx_now_ns();
-        shim_require(); shim_drain(); h = g_shim;
+        shim_require();
+        if (g_shim_finished) shim_new_stream();  // (as sample_in_1: samples behind nvx_shim_finish start a new stream)
+        shim_drain(); h = g_shim;
         for (uint64_t f = g_shim_samples / NVX_FRAME_IN; f < (g_shim_samples + numSamples) / NVX_FRAME_IN; f++) g_shim_clock.stamp(f, t_enter);
         g_shim_samples += numSamples;
     }

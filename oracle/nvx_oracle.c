@@ -317,7 +317,13 @@ static void bs_sample(nvxo_dec *d, double ds)              /* decoder.C:142-255 
 
 static int bd_sample(nvxo_dec *d, double sampleR, double sampleI)   /* decoder.C:73-137 */
 {
-    d->bd_seq_nbr++;
+    /* decoder.C:75 `bd_seq_nbr ++;` on the `int` of decoder.h:60, for ever: after 2^31 samples at 900 S/s -- 27.6 days -- it
+     * passes INT_MAX.  That is undefined behaviour in the reference; what its x86-64 build DOES is wrap to INT_MIN (an
+     * `add` on a memory operand), and that is stated here without the undefined behaviour.  From then on the remainders
+     * of decoder.C:85 are -8..0, which equal a sync offset (0..8) only when both are 0: the reference's decoder falls
+     * nearly silent for the next 27.6 days.  The PRODUCT does not copy this ("Deviations"): its bit phase
+     * is a function of the sample's position.  tests/test_deviations.py pins this line against the compiled reference. */
+    d->bd_seq_nbr = (int)((unsigned)d->bd_seq_nbr + 1u);
     if (d->status == ST_INIT) return 0;
     if (d->status == ST_SYNCED_WAIT) {
         if ((d->bd_seq_nbr % NVXO_SPB) == d->bit_sync_offset) { d->status = ST_BIT_START; d->burn_count = 0; }
@@ -383,6 +389,20 @@ size_t nvxo_decode_with(const double *y3, size_t n3, char *bits_out, nvxo_atan2_
         if (b) bits_out[nb++] = (char)b;
     }
     if (dphi_mismatch) *dphi_mismatch = mism;
+    return nb;
+}
+
+/* test probe (tests/test_deviations.py): nvxo_decode with the decoder's bd_seq_nbr set to `value` in front of sample
+ * `at` -- the state 27.6 days of running reach by themselves (see bd_sample) */
+size_t nvxo_decode_inject(const double *y3, size_t n3, char *bits_out, size_t at, int value, int *bd_seq_nbr_at)
+{
+    nvxo_dec d; nvxo_dec_init(&d);
+    size_t nb = 0;
+    for (size_t k = 0; k < n3; k++) {
+        if (k == at) { if (bd_seq_nbr_at) *bd_seq_nbr_at = d.bd_seq_nbr; d.bd_seq_nbr = value; }
+        int b = nvxo_dec_push(&d, y3[2 * k], y3[2 * k + 1]);
+        if (b) bits_out[nb++] = (char)b;
+    }
     return nb;
 }
 
@@ -677,6 +697,20 @@ void nvxo_pipe_free(nvxo_pipe *p)
 }
 
 void nvxo_pipe_set_charlayer(nvxo_pipe *p, int enabled) { p->charlayer = enabled; }
+
+/* What calling the reference's init functions AGAIN, in mid-stream, does to its statics (test probe: the product does
+ * not copy this, DESIGN.md "Deviations"; pinned against the compiled reference by tests/test_deviations.py):
+ *   which & 1  init_fir_filter1() (fir1cpp.C:65-77): FIR1's ring zeroed, its write pointer and decimation counter 0 --
+ *              nothing else;
+ *   which & 2  init_fir2_wrapper() -> init_fir_filter2() (nav_sched.C:19-22, fir2cpp.C:90-110): the 518 chain's FIR2
+ *              ring, pointer and counter, and the mixer index BOTH chains share (fir2cpp.C:7) -- never the 490
+ *              chain's FIR2 statics (fir2cpp.C:80-83), FIR3, the decoders or the character layers. */
+static void stage_clear(fir_stage *s) { s->phase = 0; memset(s->work, 0, (size_t)(s->T - 1) * sizeof(v2d)); }
+void nvxo_pipe_reinit(nvxo_pipe *p, int which)
+{
+    if (which & 1) stage_clear(&p->f1);
+    if (which & 2) { stage_clear(&p->ch[0].f2); p->mix_idx = 0; }
+}
 void nvxo_pipe_tap_y3(nvxo_pipe *p, int c, double *buf, size_t cap_pairs, size_t *count)
 {
     p->ch[c].tap = buf; p->ch[c].tap_cap = cap_pairs; p->ch[c].tap_count = count;

@@ -83,6 +83,9 @@ int  nvxo_dec_push(nvxo_dec *d, double I, double Q);
 /* whole-array convenience: bits_out must hold n3 chars; returns number of bits */
 size_t nvxo_decode(const double *y3, size_t n3, char *bits_out, double *dphi_out);
 void nvxo_bitfilter_table(float fR[5], float fI[5]);
+/* test probe: nvxo_decode with bd_seq_nbr (decoder.h:60) set to `value` in front of sample `at`; *bd_seq_nbr_at (optional)
+ * receives the value it had there                                                                                    */
+size_t nvxo_decode_inject(const double *y3, size_t n3, char *bits_out, size_t at, int value, int *bd_seq_nbr_at);
 /* test hook: same as nvxo_decode but with the discriminator's atan2 supplied by the caller
  * (NULL = libm).  Used to measure whether replacing glibc's atan2 by another one that
  * differs in the last bit ever changes a decoded bit.                                    */
@@ -114,6 +117,8 @@ void       nvxo_pipe_set_stage0(nvxo_pipe *p, int order);
 const char *nvxo_pipe_bits(nvxo_pipe *p, int chain, size_t *n);
 /* optional seam taps: append every y3 sample of chain c to a caller buffer */
 void       nvxo_pipe_tap_y3(nvxo_pipe *p, int chain, double *buf, size_t cap_pairs, size_t *count);
+/* test probe: the reference's init functions called again in mid-stream (which & 1: init_fir_filter1, & 2: init_fir2_wrapper) */
+void       nvxo_pipe_reinit(nvxo_pipe *p, int which);
 /* when set, the character layer is skipped (bit-level runs) */
 void       nvxo_pipe_set_charlayer(nvxo_pipe *p, int enabled);
 

@@ -15,11 +15,22 @@
 //   SEAM_DEC   decoder.o only, fed doubles, bsm recorded-> bits
 //   SEAM_SM    nav_b_sm.o only, fed bits                -> messages + stdout
 //
-// usage: ref_<seam> <input.bin> <output-prefix>
+// usage: ref_<seam> <input.bin> <output-prefix> [probe ...]
 //   input  : interleaved int16 I,Q (FULL/BITS/FIR*), interleaved double I,Q
 //            (DEC) or ASCII 'B'/'Y' characters (SM)
 //   output : <prefix>.<name>.bin files described next to each writer below.
 // The reference's own printf tracing goes to stdout untouched.
+//
+// Two probes of behaviour the product deliberately does NOT copy ("Deviations"):
+//   ref_full | ref_bits  in out reinit <n> <which>
+//       call the reference's init functions again in front of input sample n, the way a second
+//       init_dsp() / init_fir2_wrapper() of capt_sched.c (:552-555, :612) would:
+//       which = 1 init_fir_filter1(), 2 init_fir2_wrapper(), 3 both, in that order.
+//   ref_dec              in out inject <n> <value>
+//       set the decoder's private `int bd_seq_nbr` (decoder.h:60) to <value> in front of 900 S/s
+//       sample n -- what 27.6 days of running bring about by themselves (decoder.C:75: it is
+//       incremented for ever).  The member is reached by giving THIS translation unit a public view
+//       of the class; decoder.o is the unmodified reference object and the layout is the same.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +81,11 @@ extern "C" int add_message(char *bbbb, char *message, int freq)
 }
 #endif
 
+#if defined(SEAM_DEC)
+#define private public             /* the inject probe (above): this TU only; decoder.o is the reference's own */
+#include "decoder.h"
+#undef private
+#endif
 #if defined(SEAM_BITS) || defined(SEAM_DEC)
 #include "decoder.h"
 static std::vector<char> g_bits518, g_bits490;
@@ -128,9 +144,13 @@ extern "C" void init_fir2_wrapper();
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s input.bin out-prefix\n", argv[0]); return 2; }
+    if (argc != 3 && argc != 6) { fprintf(stderr, "usage: %s input.bin out-prefix [reinit n which | inject n value]\n", argv[0]); return 2; }
     g_prefix = argv[2];
     std::vector<char> in = read_all(argv[1]);
+    const std::string probe = argc == 6 ? argv[3] : "";
+    const size_t probe_at = argc == 6 ? (size_t)strtoull(argv[4], nullptr, 10) : (size_t)-1;
+    const long probe_arg = argc == 6 ? strtol(argv[5], nullptr, 10) : 0;
+    (void)probe_at; (void)probe_arg;
 
 #if defined(SEAM_FULL) || defined(SEAM_BITS) || defined(SEAM_FIR1) || defined(SEAM_FIR2) || defined(SEAM_FIR3)
     const int16_t *iq = (const int16_t *)in.data();
@@ -151,8 +171,15 @@ int main(int argc, char **argv)
     init_fir_filter1();                                    // capt_sched.c:552-555
     init_fir2_wrapper();                                   // capt_sched.c:612
 #endif
-    for (size_t n = 0; n < npairs; n++)                    // capt_sched.c:509-513
+    for (size_t n = 0; n < npairs; n++) {                  // capt_sched.c:509-513
+#if defined(SEAM_FULL) || defined(SEAM_BITS)
+        if (probe == "reinit" && n == probe_at) {
+            if (probe_arg & 1) init_fir_filter1();
+            if (probe_arg & 2) init_fir2_wrapper();
+        }
+#endif
         sample_in_1((double)iq[2 * n], (double)iq[2 * n + 1]);
+    }
 #endif
 
 #if defined(SEAM_DEC)
@@ -160,7 +187,10 @@ int main(int argc, char **argv)
     static decoder dec(&sm);
     const double *y3 = (const double *)in.data();
     size_t n3 = in.size() / 16;
-    for (size_t n = 0; n < n3; n++) dec.sample_in(y3[2 * n], y3[2 * n + 1]);
+    for (size_t n = 0; n < n3; n++) {
+        if (probe == "inject" && n == probe_at) dec.bd_seq_nbr = (int)probe_arg;
+        dec.sample_in(y3[2 * n], y3[2 * n + 1]);
+    }
 #endif
 
 #if defined(SEAM_SM)

@@ -83,6 +83,7 @@ int main()
     int devices[n_members] = { 0, 0, 0, 0 };
     Seen seen;
     nvx_config cfg{};
+    cfg.struct_size = sizeof cfg;
     cfg.n_streams = total; cfg.max_frames = 1; cfg.on_message = sink; cfg.user = &seen;
     nvx_group *g = nullptr;
     if (nvx_group_create(devices, n_members, &cfg, &g) != NVX_OK || nvx_group_size(g) != n_members) return 2;

@@ -35,7 +35,8 @@ for name, res, args in [
     ("nvxo_fir1", _sz, [_vp, _sz, _vp]), ("nvxo_mix", None, [_vp, _sz, _i, _vp]),
     ("nvxo_fir2", _sz, [_vp, _sz, _vp]), ("nvxo_fir3", _sz, [_vp, _sz, _vp]),
     ("nvxo_mixer_table", None, [_vp, _vp]), ("nvxo_bitfilter_table", None, [_vp, _vp]),
-    ("nvxo_decode", _sz, [_vp, _sz, _vp, _vp]), ("nvxo_decode_with", _sz, [_vp, _sz, _vp, _vp, C.POINTER(_sz)]),
+    ("nvxo_decode", _sz, [_vp, _sz, _vp, _vp]), ("nvxo_decode_inject", _sz, [_vp, _sz, _vp, _sz, _i, C.POINTER(_i)]),
+    ("nvxo_pipe_reinit", None, [_vp, _i]), ("nvxo_decode_with", _sz, [_vp, _sz, _vp, _vp, C.POINTER(_sz)]),
     ("nvxo_sm_new", _vp, [_i, MSG_FN, _vp]), ("nvxo_sm_free", None, [_vp]), ("nvxo_sm_bit", None, [_vp, C.c_char]),
     ("nvxo_sm_trace", C.c_char_p, [_vp, C.POINTER(_sz)]),
     ("nvxo_pipe_new", _vp, [_i, _i, _i, MSG_FN, _vp]), ("nvxo_pipe_free", None, [_vp]),
@@ -121,6 +122,16 @@ def decode(y3: np.ndarray) -> Tuple[str, np.ndarray]:
     return bits.raw[:n].decode("ascii"), dphi
 
 
+def decode_inject(y3: np.ndarray, at: int, value: int) -> Tuple[str, int]:
+    """nvxo_decode with the decoder's `int bd_seq_nbr` (decoder.h:60) set to `value` in front of sample `at`.
+    Returns (bits, the value the counter had there)."""
+    y3 = np.ascontiguousarray(y3, dtype=np.float64).reshape(-1, 2)
+    bits = C.create_string_buffer(y3.shape[0] + 1)
+    was = _i(0)
+    n = L.nvxo_decode_inject(_p(y3), y3.shape[0], bits, at, value, C.byref(was))
+    return bits.raw[:n].decode("ascii"), was.value
+
+
 def decode_with(y3: np.ndarray, atan2_fn_ptr) -> Tuple[str, int]:
     """Decoder restatement with a caller-supplied atan2 (C function pointer, or None for libm).
     Returns (bits, number of samples whose delta-phi differed from libm's)."""
@@ -191,6 +202,10 @@ class Pipe:
         assert raw.shape[0] % 8 == 0
         L.nvxo_pipe_push_raw(self._h, _p(raw), raw.shape[0] // 8)
 
+    def reinit(self, which: int) -> None:
+        """The reference's init functions called again in mid-stream (1: init_fir_filter1, 2: init_fir2_wrapper, 3: both)."""
+        L.nvxo_pipe_reinit(self._h, which)
+
     def set_stage0(self, order: int) -> None:
         L.nvxo_pipe_set_stage0(self._h, order)
 
@@ -258,12 +273,14 @@ def have_ref() -> bool:
     return (REF / "ref_full").exists()
 
 
-def run_ref(seam: str, data: bytes) -> Dict[str, bytes]:
-    """Run oracle/_ref/ref_<seam> on `data`; returns {output name: bytes, 'stdout': bytes}."""
+def run_ref(seam: str, data: bytes, probe: Tuple = (), ref_dir: Path | None = None) -> Dict[str, bytes]:
+    """Run oracle/_ref/ref_<seam> on `data`; returns {output name: bytes, 'stdout': bytes}.
+    probe: ("reinit", n, which) for the full / bits seams, ("inject", n, value) for the decoder seam
+    (oracle/ref_seams/ref_harness.cpp); ref_dir: seams built elsewhere (another set of compiler flags)."""
     with tempfile.TemporaryDirectory() as td:
         inp = Path(td) / "in.bin"
         inp.write_bytes(data)
-        r = subprocess.run([str(REF / f"ref_{seam}"), str(inp), str(Path(td) / "o")], check=True, capture_output=True)
+        r = subprocess.run([str((ref_dir or REF) / f"ref_{seam}"), str(inp), str(Path(td) / "o"), *[str(a) for a in probe]], check=True, capture_output=True)
         out = {"stdout": r.stdout}
         for f in Path(td).glob("o.*.bin"):
             out[f.name[2:-4]] = f.read_bytes()
