@@ -74,6 +74,42 @@ def flops_per_sample(chains: int, fir3_inside: bool = True) -> float:
     return FLOP_FIR1 + chains * (FLOP_PER_CHAIN - (0.0 if fir3_inside else FLOP_FIR3))
 
 
+# ---- what the fused wideband kernel's fp64 roof fraction is made of (r6) -----------------------------------------
+# Timing-only elimination probes on the shipped form of nvx_wideband_fused (profiles/r05/b0_fused_elimination_probes.txt:
+# three interleaved rounds, 512 streams x 12 frames): the phases of a pass ADD -- they run one after the other behind the
+# barriers.  Shares of the kernel's time: removing the cascade pass leaves 6.47 of 17.889 ms, removing the channeliser's
+# arithmetic leaves 14.141, removing both barriers 16.642.
+WB_SHARE_CASCADE = round(1 - 6.470 / 17.889, 3)         # 0.638: FIR1, mixers, FIR2 of 8 sub-bands x 2 chains -- all of the credited fp64 work
+WB_SHARE_CHANNELISER = round(1 - 14.141 / 17.889, 3)    # 0.210: integer arithmetic that earns no fp64 credit
+WB_SHARE_BARRIERS = round(1 - 16.642 / 17.889, 3)       # 0.070
+# Vector instructions of the channeliser phase (nvx_pfb.h, nvx_pfb_instant_split: a lane pair per output instant, one
+# component each), counted in the compiled kernel between its two barriers (tests/test_isa.py holds the count): 128 per
+# (instant, component) -- 48 v_dot2c_i32_i16 (one tap on one sample each), 16 shifts, 27 adds / subs, 8 v_med3 clamps, 8
+# v_cvt_f64_i32, 8 moves, 5 DPP exchanges with the partner lane, two 64-bit products for the 45-degree twiddles -- beside 12
+# ds_read_b128 and 8 ds_write_b64; two components, eight raw samples per instant.
+WB_CHANNELISER_VALU_PER_LANE = 128
+WB_INT_OPS_PER_RAW_SAMPLE = WB_CHANNELISER_VALU_PER_LANE * 2 / 8          # 32
+
+
+def wideband_decomposition(frac, fps):
+    """What a bare roof fraction of nvx_wideband_fused hides: the part of the kernel that does the credited fp64 work runs
+    at frac / WB_SHARE_CASCADE of the roof (the efficiency of the stand-alone 252 kS/s kernel, variant_a), and the
+    channeliser's integer instructions -- the same issue slots as fp64 ones on this chip, 4 cycles per wave64 -- are not in
+    the numerator at all."""
+    if not frac:
+        return None
+    return {"source": "profiles/r05/b0_fused_elimination_probes.txt: timing-only probe builds of the shipped kernel form; static shares applied to this run's time",
+            "share_of_kernel_time": {"cascade_pass": WB_SHARE_CASCADE, "channeliser_arithmetic": WB_SHARE_CHANNELISER, "barriers": WB_SHARE_BARRIERS,
+                                     "rest": round(1 - WB_SHARE_CASCADE - WB_SHARE_CHANNELISER - WB_SHARE_BARRIERS, 3)},
+            "cascade_pass_frac_of_fp64_roof": round(frac / WB_SHARE_CASCADE, 4),
+            "channeliser_int_ops_per_raw_sample": WB_INT_OPS_PER_RAW_SAMPLE,
+            "valu_issue_frac_counting_integer_ops": round(frac * (fps + WB_INT_OPS_PER_RAW_SAMPLE) / fps, 4),
+            "reading": "the phases of a pass add (barriers between them): the cascade pass, which does ALL the credited fp64 operations, takes 64 % of the kernel and "
+                       "alone runs at cascade_pass_frac_of_fp64_roof (about variant_a's efficiency); the channeliser's ~32 integer vector instructions per raw "
+                       "sample cost the same issue slots as fp64 ones and earn no credit -- counted like fp64 operations the kernel issues at "
+                       "valu_issue_frac_counting_integer_ops of the roof"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,6 +542,7 @@ def leg_wideband(nv, ob, signals, W, F, device, ncpu, char_layer, steps=8, n_che
                 "roofline": {"bound": "fp64_valu", "achieved": round(tops, 2) if tops else None, "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s",
                              "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None, "flop_per_sample": round(fps, 2),
                              "hbm_gbs": round(W * n_raw * 4 / (c_ms * 1e-3) / 1e9, 1) if c_ms > 0 else None,
+                             "decomposition": wideband_decomposition(tops / FP64_NOFMA_PEAK_TOPS if tops else None, fps),
                              "note": "the fp64 operations the kernel itself executes (FIR1, mixers, FIR2 of both chains; since r4 FIR3 -- 2.03 of the path's "
                                      "55.46 operations per sample -- is nvx_fir3, fir3_avg_launch_ms, beside the next launch); the channeliser's integer work rides on top"},
                 "handoff": {"stale_detected": stale, "launches_failed_integrity": failures},
@@ -811,6 +848,7 @@ def run_wideband(args, nv, signals, ranks, rank, world, device, place):
                      "achieved": round(tops, 2) if tops else None,
                      "peak": round(FP64_NOFMA_PEAK_TOPS, 1), "unit": "TFLOP/s", "frac": round(tops / FP64_NOFMA_PEAK_TOPS, 4) if tops else None,
                      "traffic": None, "flop_per_sample": round(fps, 2), "samples_per_launch": sub_samples,
+                     "decomposition": wideband_decomposition(tops / FP64_NOFMA_PEAK_TOPS if tops else None, fps),
                      "avg_launch_ms": round(casc_avg, 3), "launches": int(n_l), "demod_span_ms": round(dem_ms / max(n_l, 1), 3),
                      "handoff": {"units_waited_frac": round(w_units / max(1, w_launches * W * F ), 4),
                                  "avg_polls_per_waiting_unit": round(w_polls / max(1, w_units), 1),

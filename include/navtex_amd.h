@@ -396,7 +396,8 @@ NVX_API int   nvx_fsm_selftest(uint32_t seed, int periods);
  * happened -- unless some part of the path does not carry the clock in 64 bits.  tests/test_gpu_deviations.py uses it to
  * put a stream just below 2^31 samples, where the reference's `int bd_seq_nbr` overflows after 27.6 days
  * (receiver/decoder.h:60, decoder.C:75,85), and to walk it across.  Waits for the handle's launches; re-tags the seal of
- * the stream's carried FIR state for its new position.  Not for wideband handles (NVX_ERR_STATE).                     */
+ * the stream's carried FIR state for its new position.  Not for wideband handles, and not before the stream has been
+ * through three frames (the priming thresholds of the timing filter are the one thing that is not periodic): NVX_ERR_STATE. */
 #define NVX_CLOCK_PERIOD 163296
 NVX_API int   nvx_debug_advance_clock(nvx_handle *h, int stream, uint64_t periods);
 /* allocate (1) / release (0) the delta-phi debug buffer used by nvx_debug_dphi */

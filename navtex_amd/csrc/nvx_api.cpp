@@ -800,15 +800,15 @@ extern "C" int nvx_debug_advance_clock(nvx_handle *h, int stream, uint64_t perio
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream2));
     const unsigned long long g_old = h->g0s[stream];
+    // (the priming thresholds are the one thing that is NOT periodic: a stream that has not passed them would skip its priming)
+    if (g_old < 3 * NVX_FRAME_Y3) { nvx_set_error("nvx_debug_advance_clock: stream %d is still priming (%llu samples at 900 S/s; the timing filter is primed at 582)", stream, g_old); return NVX_ERR_STATE; }
     if (periods > (~0ull - g_old) / (unsigned long long)NVX_CLOCK_PERIOD) { nvx_set_error("nvx_debug_advance_clock: the clock would pass 2^64"); return NVX_ERR_ARG; }
     const unsigned long long g_new = g_old + periods * (unsigned long long)NVX_CLOCK_PERIOD;
     const unsigned third_old = (unsigned)(g_old / (NVX_FRAME_Y3 / 3)), third_new = (unsigned)(g_new / (NVX_FRAME_Y3 / 3));
     unsigned long long seal[2];
     uint8_t *entry = h->d_cstate[h->parity[stream]] + (size_t)stream * NVX_CASCADE_STATE_BYTES + (size_t)NVX_STATE_SEAL * 16;
     HIP_TRY(hipMemcpy(seal, entry, sizeof seal, hipMemcpyDeviceToHost));
-    // (position 0: nothing was ever stored, the block is nvx_reset's zeros and the kernels do not look at its seal; zeros
-    // fold to 0, so their seal at the new position is the tag alone)
-    seal[0] = (third_old ? seal[0] ^ seal_tag_host(stream, third_old) : 0ull) ^ seal_tag_host(stream, third_new);
+    seal[0] ^= seal_tag_host(stream, third_old) ^ seal_tag_host(stream, third_new);
     seal[1] = ((unsigned long long)(unsigned)stream << 32) | third_new;
     HIP_TRY(hipMemcpy(entry, seal, sizeof seal, hipMemcpyHostToDevice));
     h->g0s[stream] = g_new;

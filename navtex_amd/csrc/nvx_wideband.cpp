@@ -1,5 +1,6 @@
-// nvx_wideband.cpp -- stand-alone channeliser entry points (header section G); the handle's wideband
-// mode calls nvx_channelise_resident from nvx_launch_locked.
+// nvx_wideband.cpp -- the STAND-ALONE channeliser's entry points (header section G: nvx_channelise_resident, its timing, the
+// handle's stream).  A wideband HANDLE does not come through here: its launches run nvx_wideband_fused + nvx_fir3
+// (nvx_api.cpp, nvx_launch_locked), where the sub-bands never leave the LDS.
 #include "nvx_handle.h"
 
 // ------------------------------------------------------------ wideband front-end

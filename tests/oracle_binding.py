@@ -291,21 +291,21 @@ def have_ref_wav() -> bool:
     return (REF / "ref_wav").exists()
 
 
-def ref_wav_write(frames: np.ndarray, rate: int) -> bytes:
+def ref_wav_write(frames: np.ndarray, rate: int, ref_dir: Path | None = None) -> bytes:
     """The reference's wav.c writes `frames` ([n, 2] int16) the way capt_sched.c:91-95,516 does; returns the file bytes."""
     with tempfile.TemporaryDirectory() as td:
         f = Path(td) / "frames.bin"
         f.write_bytes(np.ascontiguousarray(frames, dtype=np.int16).tobytes())
-        subprocess.run([str(REF / "ref_wav"), "write", str(f), str(Path(td) / "o.wav"), str(rate)], check=True)
+        subprocess.run([str((ref_dir or REF) / "ref_wav"), "write", str(f), str(Path(td) / "o.wav"), str(rate)], check=True)
         return (Path(td) / "o.wav").read_bytes()
 
 
-def ref_wav_read(path: str):
+def ref_wav_read(path: str, ref_dir: Path | None = None):
     """The reference's wav_open/wav_get_*/wav_read (wav.c:469-528) on a file; returns ((format, channels, rate,
     sample_size, length), frame bytes)."""
     with tempfile.TemporaryDirectory() as td:
         out = Path(td) / "frames.bin"
-        r = subprocess.run([str(REF / "ref_wav"), "read", str(path), str(out)], check=True, capture_output=True)
+        r = subprocess.run([str((ref_dir or REF) / "ref_wav"), "read", str(path), str(out)], check=True, capture_output=True)
         return tuple(int(v) for v in r.stdout.split()), out.read_bytes()
 
 

@@ -255,7 +255,7 @@ def test_one_stream_starts_anew_while_the_others_carry_on(nv, oracle, tmp_path):
 def _wide_input(nv, seed, n):
     """A 2.016 MS/s input with sixteen carriers (8 sub-bands x +-14 kHz), each with its own text, timing and phase."""
     car = [dict(freq_hz=(k * 252000 if k < 4 else (k - 8) * 252000) + off, bits=nv.sitor_encode(f"ZCZC R{k}{c}{seed % 10}\nRESET {seed}\nNNNN\n", 4),
-                bit_offset=977 * (2 * k + c + 1) + 31 * seed, phase0=k * 1234567 + c + seed, amplitude=1800) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
+                bit_offset=(977 * (2 * k + c + 1) + 31 * seed) % 20160 | 1, phase0=k * 1234567 + c + seed, amplitude=1800) for k in range(8) for c, off in ((0, 14000), (1, -14000))]
     return nv.synth_host(nv.make_stream(car, seed=seed, noise_amp=300), nv.RATE_RAW, n)
 
 

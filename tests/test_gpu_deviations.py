@@ -134,8 +134,9 @@ def test_clock_hook_refuses_what_it_cannot_do(nv):
 
 
 def test_one_of_two_streams_far_ahead_in_time(nv, oracle):
-    """The same hook on ONE stream of a two-stream handle, from position 0 (nothing stored yet: the zero block is sealed
-    for its new position): the streams are then 27 days apart, launches carry lists, both decode the oracle's bits."""
+    """The same hook on ONE stream of a two-stream handle: the streams are then 27 days apart, launches carry lists with
+    each stream's own clock, both decode the oracle's bits.  (A stream that is still priming is refused: the priming
+    thresholds are the one thing derived from the clock that is not periodic.)"""
     import signals
     iqs, refs = [], []
     for s in range(2):
@@ -143,8 +144,12 @@ def test_one_of_two_streams_far_ahead_in_time(nv, oracle):
         iqs.append(nv.synth_host(st, nv.RATE_IN, 8 * nv.FRAME_IN))
         r = oracle.Pipe(chain_mask=1, charlayer=False); r.push(iqs[s]); refs.append(r)
     with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=False) as p:
+        with pytest.raises(nv.NvxError):
+            p.debug_advance_clock(1, 13150)                   # position 0: still priming
+        head = 3 * nv.FRAME_IN
+        p.push(0, iqs[0][:head]); p.push(1, iqs[1][:head]); p.flush()
         p.debug_advance_clock(1, 13150)
-        for k in range(0, 8 * nv.FRAME_IN, 50000):
+        for k in range(head, 8 * nv.FRAME_IN, 50000):
             p.push(0, iqs[0][k:k + 50000]); p.push(1, iqs[1][k:k + 50000])
         p.flush()
         assert p.stream_stats(1)[1] - p.stream_stats(0)[1] == 13150 * 567

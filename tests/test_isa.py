@@ -45,6 +45,26 @@ def test_cascade_has_no_fused_multiply_add(isa):
     assert "ds_read2_b64" not in fir3 and "ds_read2st64_b64" not in fir3
 
 
+def test_channeliser_phase_instruction_count_behind_the_bench_lines_decomposition(isa):
+    """bench.py's wideband.roofline.decomposition quotes the channeliser's vector instructions per raw sample
+    (WB_CHANNELISER_VALU_PER_LANE: per output instant and component, between the fused kernel's two barriers): held here
+    against the compiled kernel, so that the figure in the line cannot drift away from the code."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_isa", ROOT / "bench.py"); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    kernels, _ = isa
+    fused = next(v for k, v in kernels.items() if "nvx_wideband_fused" in k)
+    lines = [l.strip() for l in fused.splitlines() if l.strip() and not l.strip().startswith((";", "."))]
+    dots = [i for i, l in enumerate(lines) if l.startswith("v_dot2")]
+    bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+    assert len(dots) == 48                               # one (tap, sample) product per instruction: 48 taps
+    lo, hi = max(b for b in bars if b < dots[0]), min(b for b in bars if b > dots[-1])
+    phase = lines[lo:hi]
+    valu = sum(1 for l in phase if l.startswith("v_"))
+    assert abs(valu - bench.WB_CHANNELISER_VALU_PER_LANE) <= 4, valu
+    assert sum(1 for l in phase if l.startswith("ds_read_b128")) == 12 and sum(1 for l in phase if l.startswith("ds_write_b64")) == 8
+    assert not any(l.startswith(("v_mul_f64", "v_add_f64")) for l in phase)     # integer work only: no credited fp64 operation in this phase
+
+
 def test_roofline_kernel_uses_wide_nt_loads_and_no_scratch(isa):
     kernels, meta = isa
     main = next(v for k, v in kernels.items() if "nvx_fir_cascadeILb1ELi1EE" in k)
