@@ -355,6 +355,51 @@ def test_several_threads_push_into_one_handle(nv, oracle):
             assert p.stream_stats(s)[1] == F
 
 
+@pytest.mark.parametrize("eager", [False, True], ids=["lock_step", "eager"])
+def test_streams_ended_under_their_pushers(nv, oracle, eager):
+    """nvx_stream_finish / nvx_finish while other threads are in the middle of push calls on the very streams that end (the
+    advisor's r5 finding: a pusher that had released the handle's lock inside its loop went on staging samples into the
+    ended stream, which then vetoed every launch of the handle).  A push call is atomic against the end of its stream:
+    accepted whole and decoded, or refused whole with NVX_ERR_STATE.  Four streams, a pusher thread each, pushes from a few
+    hundred samples to several frames; stream 1 is ended alone while all four run, the others a little later all at once.
+    Every stream's bits == the oracle on exactly the samples its accepted calls carried; the streams that were not yet
+    ended kept launching in between; only NVX_ERR_STATE was ever seen, and only behind an end."""
+    S, F = 4, 40
+    iqs = [nv.synth_host(signals.stream_params(nv, 8800 + s, nv.RATE_IN, n_phasing=12)[0], nv.RATE_IN, F * nv.FRAME_IN) for s in range(S)]
+    accepted, wrong = [0] * S, []
+    with nv.Pipeline(n_streams=S, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=False,
+                     eager_launch=eager, stall_timeout_ms=-1) as p:
+        def feed(s):
+            rng = np.random.default_rng(50 + s)
+            pos = 0
+            while pos < F * nv.FRAME_IN:
+                m = int(min(F * nv.FRAME_IN - pos, rng.choice([300, 4000, 30000, 200000, 3 * nv.FRAME_IN + 17])))
+                try:
+                    p.push(s, iqs[s][pos:pos + m])
+                except nv.NvxError as e:
+                    if e.code != -5: wrong.append((s, e.code))       # NVX_ERR_STATE: the stream ended under this pusher
+                    return
+                pos += m; accepted[s] = pos
+                time.sleep(0.002)                                   # (a pace at which the ends below fall into the middle of the inputs)
+        threads = [threading.Thread(target=feed, args=(s,)) for s in range(S)]
+        for th in threads: th.start()
+        time.sleep(0.02)
+        p.finish(1)
+        frames_then = p.stream_stats(0)[1]
+        time.sleep(0.025)
+        frames_later = p.stream_stats(0)[1]
+        p.finish()
+        for th in threads: th.join()
+        assert not wrong, wrong
+        assert frames_later > frames_then, "the handle made no progress behind the ended stream"
+        for s in range(S):
+            ref = oracle.Pipe(chain_mask=1, charlayer=False)
+            ref.push(iqs[s][:accepted[s]])
+            assert p.bits(s, 0) == ref.bits(0), f"stream {s}: {accepted[s]} samples accepted"
+        assert accepted[1] < F * nv.FRAME_IN and accepted[1] < max(accepted), accepted        # stream 1 really ended in mid-input, before the others
+        assert p.integrity_stats()[:2] == (0, 0)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_randomized_ragged_wideband_inputs(nv, oracle, seed):
     """The fused wideband kernel with participant lists, randomised: two or three 2.016 MS/s inputs (16 carriers each) fed
