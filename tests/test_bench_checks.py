@@ -61,6 +61,7 @@ def test_traffic_record_is_per_shape_front_end_and_kernel_source(monkeypatch):
     """roofline.traffic is a static PMC record: quoted only for the (streams, frames, stage-0 order) it was taken on AND only
     while the kernel's sources are the ones it was taken on (an entry carries their hash); otherwise null, with the reason."""
     import bench
+    from benchlib import roofline                    # (tools/benchlib: where traffic_record lives and looks its hash function up)
     rec = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
     assert {(e["streams"], e["frames"], e.get("stage0_order", 1)) for e in rec["entries"]} >= {(4096, 12, 1), (4096, 12, 3)}
     for e in rec["entries"]:
@@ -68,11 +69,11 @@ def test_traffic_record_is_per_shape_front_end_and_kernel_source(monkeypatch):
         assert e["bytes_per_launch"] == int(e["fetch_size_kb"] * 1024 * 2 + e["write_size_kb"] * 1024)
         assert 1.0 <= e["bytes_per_launch"] / (4 * e["streams"] * e["frames"] * 645120) < 1.03
         # taken on these sources: quoted ...
-        monkeypatch.setattr(bench, "kernel_source_hash", lambda h=e.get("kernel_source_sha256_16"): h)
+        monkeypatch.setattr(roofline, "kernel_source_hash", lambda h=e.get("kernel_source_sha256_16"): h)
         b, src = bench.traffic_record(*shape)
         assert b == e["bytes_per_launch"] and "static" in src
         # ... on others: not
-        monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0123456789abcdef")
+        monkeypatch.setattr(roofline, "kernel_source_hash", lambda: "0123456789abcdef")
         b, why = bench.traffic_record(*shape)
         assert b is None and why.startswith("null") and "kernel sources" in why
     monkeypatch.undo()
