@@ -76,6 +76,7 @@ static void append(char *buf, size_t *len, const char *src, size_t n)
 
 void nvx_sitor_reset(nvx_sitor *s)                         /* nav_b_sm.C:16-42 init() */
 {
+    if (!s) return;                                        /* (every exported entry point takes a NULL object as a no-op) */
     s->matched = 0; s->slot = SLOT_SEARCH; s->figures = 0;
     s->nbits = 0; s->dx_pos = 0; s->dx_full = 0;
     s->err_count = 0; s->err_pos = 0; s->err_full = 0;
@@ -94,7 +95,7 @@ nvx_sitor *nvx_sitor_new(int freq, nvx_sitor_msg_fn on_msg, void *user)
     nvx_sitor_reset(s);
     return s;
 }
-void nvx_sitor_set_trace(nvx_sitor *s, nvx_sitor_trace_fn fn, void *user) { s->on_trace = fn; s->trace_user = user; }
+void nvx_sitor_set_trace(nvx_sitor *s, nvx_sitor_trace_fn fn, void *user) { if (!s) return; s->on_trace = fn; s->trace_user = user; }
 void nvx_sitor_free(nvx_sitor *s) { free(s); }
 
 static void abort_message(nvx_sitor *s)                    /* nav_b_sm.C:44-52 */
@@ -238,6 +239,7 @@ static void receive_code(nvx_sitor *s, unsigned code)      /* nav_b_sm.C:150-262
 
 void nvx_sitor_receive_bit(nvx_sitor *s, char bit)         /* nav_b_sm.C:266-634 */
 {
+    if (!s) return;
     if (s->enabled) {
         /* the reference shifts a signed char; only 7 bits are ever collected
          * between two clears, so an unsigned accumulator is equivalent        */
@@ -268,6 +270,7 @@ void nvx_sitor_receive_bit(nvx_sitor *s, char bit)         /* nav_b_sm.C:266-634
 
 void nvx_sitor_receive_bits(nvx_sitor *s, const char *bits, size_t n)
 {
+    if (!s || !bits) return;
     for (size_t i = 0; i < n; i++)
         if (bits[i] == 'B' || bits[i] == 'Y') nvx_sitor_receive_bit(s, bits[i]);
 }
@@ -298,6 +301,7 @@ static size_t put_code(char *bits, size_t cap, size_t at, unsigned code)
 size_t nvx_sitor_encode(const char *text, int n_phasing, char *bits, size_t cap)
 {
     /* 1. text -> code sequence with shift characters                         */
+    if (!text) return 0;
     size_t n = strlen(text), ncodes = 0;
     unsigned char *codes = (unsigned char *)malloc(3 * n + 16);
     if (!codes) return 0;

@@ -99,6 +99,31 @@ def test_links_against_a_c_program_with_its_own_add_message(nv, tmp_path):
     subprocess.run([str(exe)], check=True)
 
 
+def test_null_objects_are_errors_or_no_ops_never_crashes(nv, tmp_path):
+    """tests/harness/null_args.c calls every entry point that takes an object or a pointer it must read with NULL, in a
+    process of its own (a crash would be a signal, not a Python error): error codes and no-ops throughout.  The entry points
+    the program does NOT call are listed here with the reason, and the two lists together are the header's."""
+    src = ROOT / "tests" / "harness" / "null_args.c"
+    exe = tmp_path / "null_args"
+    lib = ROOT / "navtex_amd"
+    subprocess.run(["gcc", "-O1", "-g", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe), f"-L{lib}", "-lnavtex_amd",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "null-safety ok" in out.stdout, (out.stdout[-1500:], out.stderr[-500:], out.returncode)
+    not_called = {
+        # the reference-shaped void surface creates the GPU singleton on first use (aborts without a device, by contract)
+        "init_fir_filter1", "sample_in_1", "init_fir2_wrapper", "nvx_StreamACallback", "add_message",
+        # no object argument: plain values, or device memory helpers that need a device
+        "nvx_last_error", "nvx_version", "nvx_wav_err", "nvx_config_default", "nvx_sample_to_int16", "nvx_device_count", "nvx_device_alloc", "nvx_device_free",
+        "nvx_memcpy_h2d", "nvx_memcpy_d2h", "nvx_device_sync", "nvx_stream_create", "nvx_stream_destroy", "nvx_synth_device",
+        "nvx_channelise_resident", "nvx_bind_thread_to_device", "nvx_sitor_new",
+    }
+    text = src.read_text()
+    called = {sym for sym in declared_symbols() if re.search(rf"\b{sym}\(", text)}
+    assert called | not_called == set(declared_symbols()), sorted(set(declared_symbols()) - called - not_called)
+    assert not (called & (not_called - {"nvx_sample_to_int16"}))
+
+
 def test_device_entry_points_fail_loudly_without_a_gpu(nv):
     if nv.device_count() > 0:
         pytest.skip("a GPU is present")
