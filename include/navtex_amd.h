@@ -346,7 +346,12 @@ NVX_API size_t nvx_poll_bits(nvx_handle *h, int stream, int chain, char *out, si
  * state from the previous call.  Successive calls may name different streams:
  * the library orders a launch behind its predecessor (the carried state makes
  * launches of one handle sequential by nature).  Asynchronous; bits stay on
- * the device until nvx_fetch_bits.                                           */
+ * the device until nvx_fetch_bits.
+ * Before anything is launched the span the kernels will read -- up to the last
+ * stream's last frame -- is held against the allocation d_iq lies in
+ * (hipMemGetAddressRange): a launch that would read past its end is refused
+ * with NVX_ERR_ARG instead of faulting on the device.  nvx_synth_device and
+ * nvx_channelise_resident check their operands the same way.                 */
 NVX_API int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitch_samples,
                                  size_t first_frame, int n_frames, void *hip_stream);
 /* synchronise, run the character layer (if enabled) on the new bits          */

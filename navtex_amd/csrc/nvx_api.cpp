@@ -43,6 +43,18 @@ int nvx_select_device(int device)
 }
 
 
+int nvx_check_device_span(const void *p, size_t bytes, const char *what)
+{
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return NVX_OK; }
+    const size_t off = (size_t)((const char *)p - (const char *)base);
+    if (off > size || bytes > size - off) {
+        nvx_set_error("%s: %zu bytes from %p leave the allocation they lie in (%zu bytes from %p): the launch would fault", what, bytes, p, size, (void *)base);
+        return NVX_ERR_ARG;
+    }
+    return NVX_OK;
+}
+
 // The character layers of different chains run on worker threads; their messages are
 // parked per slot and handed to the user's sink afterwards, in slot order, by the
 // collecting thread (the reference calls add_message from its single DSP thread).
@@ -664,6 +676,12 @@ extern "C" int nvx_process_resident(nvx_handle *h, const void *d_iq, size_t pitc
     if (!h || !d_iq) { nvx_set_error("nvx_process_resident: null argument"); return NVX_ERR_ARG; }
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (n_frames >= 1 && n_frames <= h->cfg.max_frames) {            // (nvx_launch_locked names the other argument errors)
+        // the last stream's last frame must still lie inside the caller's buffer
+        const size_t span = ((size_t)(h->n_in - 1) * pitch + (first_frame + (size_t)n_frames) * h->frame_in) * 4;
+        int rc = nvx_check_device_span(d_iq, span, "nvx_process_resident: [n_streams][pitch] input");
+        if (rc != NVX_OK) return rc;
+    }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
     return nvx_launch_locked(h, d_iq, pitch, first_frame * h->frame_in, n_frames, st);
 }

@@ -33,6 +33,12 @@
 
 // NVX_OK after hipSetDevice(device); NVX_ERR_NODEV ("no CPU path") without a HIP device
 int nvx_select_device(int device);
+// A kernel that reads or writes outside its operands faults, and a GPU fault can take the whole node with it: before a
+// launch over CALLER memory, [p, p + bytes) is held against the allocation the runtime knows p to lie in
+// (hipMemGetAddressRange; the current device must be the pointer's).  NVX_ERR_ARG when the span leaves the allocation;
+// NVX_OK when it fits -- or when the runtime does not know the pointer (no verdict possible: a suballocator's arena
+// gives a weaker check, memory of another kind none).
+int nvx_check_device_span(const void *p, size_t bytes, const char *what);
 
 // ------------------------------------------------------------------ handle
 static const int RESULT_SLOTS = 4;

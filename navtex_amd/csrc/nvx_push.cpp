@@ -184,16 +184,19 @@ static int push_common(nvx_handle *h, int stream, size_t n, F copy_in, size_t *a
 // the capture ring's consumer: a full staging set is back-pressure there, not an error
 int nvx_push_iq_partial(nvx_handle *h, int stream, const int16_t *iq, size_t n, size_t *accepted)
 {
+    if (n && !iq) { if (accepted) *accepted = 0; nvx_set_error("nvx_push_iq: null samples"); return NVX_ERR_ARG; }
     return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) { memcpy(dst, iq + 2 * off, m * 4); }, accepted);
 }
 
 extern "C" int nvx_push_iq(nvx_handle *h, int stream, const int16_t *iq, size_t n)
 {
+    if (n && !iq) { nvx_set_error("nvx_push_iq: null samples"); return NVX_ERR_ARG; }
     return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) { memcpy(dst, iq + 2 * off, m * 4); });
 }
 
 extern "C" int nvx_push_planar(nvx_handle *h, int stream, const int16_t *xi, const int16_t *xq, size_t n)
 {
+    if (n && (!xi || !xq)) { nvx_set_error("nvx_push_planar: null samples"); return NVX_ERR_ARG; }
     return push_common(h, stream, n, [&](uint32_t *dst, size_t off, size_t m) {
         for (size_t k = 0; k < m; k++)                     // interleave as capt_sched.c:120-129 does
             dst[k] = (uint32_t)(uint16_t)xi[off + k] | ((uint32_t)(uint16_t)xq[off + k] << 16);

@@ -9,6 +9,7 @@ extern "C" int nvx_synth_device(int device, const nvx_synth_stream *streams, int
         nvx_set_error("nvx_synth_device: bad argument"); return NVX_ERR_ARG;
     }
     int rc = nvx_select_device(device); if (rc != NVX_OK) return rc;
+    if ((rc = nvx_check_device_span(d_out, ((size_t)(n_streams - 1) * pitch + n) * 4, "nvx_synth_device: output")) != NVX_OK) return rc;
     const uint32_t spb = sample_rate / 100;
     std::vector<nvx_synth_desc> desc(n_streams);
     std::vector<nvx_period> pool;

@@ -42,6 +42,11 @@ extern "C" int nvx_channelise_resident(int device, const void *d_raw, size_t pit
         return NVX_ERR_ARG;
     }
     int rc = nvx_select_device(device); if (rc != NVX_OK) return rc;
+    // every operand's last element must lie inside its allocation (nvx_handle.h: a faulting kernel can take the node down)
+    if ((rc = nvx_check_device_span(d_raw, ((size_t)(n_wide - 1) * pitch_raw + first_sample + 8 * n_out) * 4, "nvx_channelise_resident: raw input")) != NVX_OK) return rc;
+    if ((rc = nvx_check_device_span(d_sub, ((size_t)(n_wide * NVX_WB_SUBBANDS - 1) * pitch_sub + sub_first + n_out) * 4, "nvx_channelise_resident: sub-band output")) != NVX_OK) return rc;
+    if (d_hist_in && (rc = nvx_check_device_span(d_hist_in, (size_t)n_wide * 40 * 4, "nvx_channelise_resident: history in")) != NVX_OK) return rc;
+    if (d_hist_out && (rc = nvx_check_device_span(d_hist_out, (size_t)n_wide * 40 * 4, "nvx_channelise_resident: history out")) != NVX_OK) return rc;
     nvx_channelise_args a{};
     a.raw = (const uint32_t *)d_raw; a.pitch_raw = pitch_raw; a.first_sample = first_sample; a.n_wide = n_wide; a.n_out = n_out;
     a.hist_in = (const uint32_t *)d_hist_in; a.hist_out = (uint32_t *)d_hist_out;

@@ -596,9 +596,26 @@ def test_error_paths(nv):
         with pytest.raises(nv.NvxError) as e:
             p.process_resident(buf, 2 * nv.FRAME_IN + 2, 0, 1)  # pitch not a multiple of 4
         assert e.value.code == -1
+        # a launch whose last stream would read past the end of the caller's buffer is refused BEFORE it is launched (a
+        # faulting kernel can take the whole node down): the buffer holds 2 streams x 2 frames at this pitch
+        p.process_resident(buf, 2 * nv.FRAME_IN, 1, 1); p.fetch()           # frames [1, 2) of both streams: the last byte of the buffer, fine
+        for pitch, first in ((2 * nv.FRAME_IN, 2), (2 * nv.FRAME_IN + 4, 1), (4 * nv.FRAME_IN, 0)):
+            with pytest.raises(nv.NvxError, match="leave the allocation") as e:
+                p.process_resident(buf, pitch, first, 1)
+            assert e.value.code == -1
+        p.process_resident(buf, 2 * nv.FRAME_IN, 0, 1); p.fetch()           # ... and the handle is none the worse for it
+        st, _ = signals.stream_params(nv, 1, nv.RATE_IN)
+        with pytest.raises(nv.NvxError, match="leave the allocation"):
+            nv.synth_device([st, st, st], nv.RATE_IN, 2 * nv.FRAME_IN, buf, 2 * nv.FRAME_IN)     # three rows into a buffer of two
+        sub = nv.DeviceBuffer(8 * 64 * 4)
+        assert nv.lib.nvx_channelise_resident(0, buf.ptr, 1024, 0, 1, 128, None, None, sub.ptr, 64, 0, None) == -1      # 128 outputs per sub-band into rows of 64
+        assert b"leave the allocation" in nv.lib.nvx_last_error()
+        sub.free()
         buf.free()
     with nv.Pipeline(n_streams=2, raw_rate=False, max_frames=1, push_mode=True) as p:
         blk = np.zeros((nv.FRAME_IN, 2), dtype=np.int16)
+        assert nv.lib.nvx_push_iq(p._h, 0, None, 16) == -1 and nv.lib.nvx_push_planar(p._h, 0, None, blk.ctypes.data, 16) == -1      # null samples
+        assert nv.lib.nvx_push_iq(p._h, 0, None, 0) == 0                                                                          # (nothing to read: fine)
         p.push(0, blk); p.push(0, blk)                 # staging holds max_frames + 1 frames per stream
         p.push(0, blk)                                  # stream 1 never delivered: since round 3 stream 0 goes on without it
         assert p.stream_stats(0)[1] >= 1 and p.stream_stats(1)[1] == 0 and p.stream_stats(0)[2] >= 1
