@@ -706,6 +706,55 @@ def test_live_capture_overrun_is_counted_not_silent(nv, oracle):
         assert p.bits(0, 0) == ref.bits(0) and len(ref.bits(0)) > 300
 
 
+def test_a_stream_ended_under_a_running_capture_ring(nv, oracle):
+    """The advisor's r5 scenario as it would happen in a receiver: nvx_stream_finish on a stream whose capture ring's consumer
+    is still feeding it.  The consumer's push in progress runs to its end and is decoded, its next push is refused whole
+    (NVX_ERR_STATE), the consumer stops and says why (nvx_capture_error); the bits are the oracle's on exactly the samples
+    the ring had handed on; the other stream of the handle, fed directly, never notices."""
+    import time
+    import signals
+    sts = [signals.stream_params(nv, 4500 + s, nv.RATE_IN)[0] for s in range(2)]
+    n = 30 * nv.FRAME_IN
+    iqs = [nv.synth_host(st, nv.RATE_IN, n) for st in sts]
+    xi, xq = np.ascontiguousarray(iqs[0][:, 0]), np.ascontiguousarray(iqs[0][:, 1])
+    with nv.Pipeline(n_streams=2, raw_rate=False, chain_mask=nv.CHAIN_518, max_frames=2, push_mode=True, char_layer=False, stall_timeout_ms=-1) as p:
+        cap = _capture(nv, p, 0.5)
+        pos = 0
+        for k in range(10):                               # the first ten frames, at a pace the consumer follows; stream 1 beside it
+            for _ in range(8):
+                m = nv.FRAME_IN // 8
+                while True:
+                    r, d, c = _stats(nv, cap)
+                    if r - d - c + m <= 100000: break
+                    time.sleep(0.0005)
+                nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap); pos += m
+            p.push(1, iqs[1][k * nv.FRAME_IN:(k + 1) * nv.FRAME_IN])
+        m = 1234                                          # (a ragged end: a stream that stops ON a frame boundary is not ended by a finish)
+        nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap); pos += m
+        deadline = time.time() + 5.0
+        while _stats(nv, cap)[2] < pos and time.time() < deadline:
+            time.sleep(0.002)
+        p.finish(0)                                       # ... ended while the ring runs
+        _r, _d, consumed_then = _stats(nv, cap)
+        assert consumed_then == pos
+        for _ in range(8):                                # the radio goes on delivering
+            m = nv.FRAME_IN // 8
+            nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap); pos += m
+        deadline = time.time() + 5.0
+        while nv.lib.nvx_capture_error(cap) == 0 and time.time() < deadline:
+            time.sleep(0.005)
+        assert nv.lib.nvx_capture_error(cap) == -5        # NVX_ERR_STATE: its stream has ended
+        _r, d, consumed = _stats(nv, cap)
+        assert d == 0 and consumed == consumed_then       # nothing was staged behind the end
+        assert nv.lib.nvx_capture_stop(cap) == -5
+        p.push(1, iqs[1][10 * nv.FRAME_IN:]); p.finish(1)                # the other stream goes on to its own end
+        ref0 = oracle.Pipe(chain_mask=1, charlayer=False); ref0.push(iqs[0][:consumed])
+        ref1 = oracle.Pipe(chain_mask=1, charlayer=False); ref1.push(iqs[1])
+        assert p.bits(0, 0) == ref0.bits(0) and len(ref0.bits(0)) > 200
+        assert p.bits(1, 0) == ref1.bits(0) and len(ref1.bits(0)) > 850
+        assert p.integrity_stats()[:2] == (0, 0)
+
+
 def test_empty_and_tiny_pushes(nv):
     with nv.Pipeline(n_streams=1, raw_rate=False, max_frames=1, push_mode=True) as p:
         p.push(0, np.zeros((0, 2), dtype=np.int16))      # empty push is a no-op
