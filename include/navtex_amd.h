@@ -312,11 +312,12 @@ NVX_API int nvx_flush(nvx_handle *h);
  * handle: nvx_flush, then ONE more launch for the streams that still hold a partial frame, each at its TRUE length --
  * the demodulator stops at the stream's last real 900 S/s sample (floor(n / 280) at 252 kS/s input, floor(n / 2240) at
  * 2.016 MS/s); no padding is decoded, no bit is withheld: the bits of a stream are then exactly the reference's on the
- * same samples, whatever the length.  A stream that held a partial frame is ENDED afterwards (its filters have run
- * past its last sample): nvx_push_* and launches that name it return NVX_ERR_STATE until nvx_reset / nvx_stream_reset.  A stream
- * that ended on a frame boundary is not ended by this (what it carries is a valid continuation; a later push goes on
- * bit-exactly) -- it is only marked inactive, so that the others' launches do not wait for it.  nvx_stream_finish: the
- * same for one stream (the whole frames of the others are launched as by nvx_flush).
+ * same samples, whatever the length.  Every stream that has had input is ENDED afterwards, whatever its length (with a
+ * partial frame its filters have run past its last sample; on a frame boundary nothing was left to launch -- one rule, so
+ * that nothing depends on a length modulo the frame): nvx_push_* and launches that name it return NVX_ERR_STATE until
+ * nvx_reset / nvx_stream_reset, and the others' launches do not wait for it.  A stream that has had no input at all has no
+ * end and is left as it is.  nvx_stream_finish: the same for one stream (the whole frames of the others are launched as
+ * by nvx_flush).
  * Against pushes on other threads a finish is atomic per push CALL: the calls in progress on the streams that are ending
  * run to their end first and are decoded; a call that arrives meanwhile waits and is then refused whole (NVX_ERR_STATE,
  * nothing staged).  The same holds for nvx_stream_reset and nvx_reset, after which the waiting call starts the new stream. */
@@ -512,10 +513,9 @@ NVX_API const char *nvx_wav_err(void);                                  /* wav.h
 /* File harness the reference lacks: open -> loop wav_read ->
  * the capt_sched.c:509-513 loop, on the GPU, ended by nvx_stream_finish: the
  * bits are the reference's on the same file, whatever its length; the stream is
- * ended afterwards -- also when the file is a whole number of frames long (a file
- * has an end; only an empty file ends nothing) -- and nvx_stream_reset / nvx_reset
- * start a new one.  Returns the number of frames (the last one may be partial) or
- * a negative error.                                                            */
+ * ended afterwards (only an empty file on a fresh stream ends nothing) and
+ * nvx_stream_reset / nvx_reset start a new one.  Returns the number of frames
+ * (the last one may be partial) or a negative error.                           */
 NVX_API int nvx_decode_wav(nvx_handle *h, int stream, const char *filename);
 
 /* ==========================================================================

@@ -250,9 +250,13 @@ static int finish_locked(nvx_handle *h, std::unique_lock<std::mutex> &lk, int st
         std::vector<int> part, n3;
         for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? h->n_in : stream + 1); s++) {
             if (h->ended[s]) continue;
-            // a stream that ends on a frame boundary is not ended by this (its state is a valid continuation: a later push goes
-            // on bit-exactly, and makes it active again) -- but it delivers nothing for now, so nobody waits for it
-            if (h->fill[s] == 0) { h->active[s] = 0; continue; }
+            // One rule for every length (r6; before, a stream that stopped exactly on a frame boundary stayed live, so whether
+            // a later push was accepted depended on the input's length modulo the frame): the end of the input ENDS the
+            // stream.  On a frame boundary nothing is left to launch; a stream that has had no input at all has no end.
+            if (h->fill[s] == 0) {
+                if (h->g0s[s] > 0) { h->ended[s] = 1; h->active[s] = 0; }
+                continue;
+            }
             const int t = (int)(h->fill[s] / per_y3);
             if (t > 0) { part.push_back(s); n3.push_back(t); }
             else { h->fill[s] = 0; h->ended[s] = 1; h->active[s] = 0; }  // too short for one more 900 S/s sample: nothing to decode
@@ -307,14 +311,9 @@ extern "C" int nvx_decode_wav(nvx_handle *h, int stream, const char *filename)
     // last sample, receiver/capt_sched.c:509-513)
     rc = nvx_stream_finish(h, stream);
     if (rc != NVX_OK) return rc;
-    // A FILE has an end whatever its length: a file of whole frames leaves nothing for nvx_stream_finish to run, but the
-    // stream is ended all the same, so that the next file on this stream needs its nvx_stream_reset as after any other
-    // length (and is never silently decoded as the continuation of this one).  An empty file ends nothing.
-    if (total > 0) {
-        std::unique_lock<std::mutex> lk(h->mu);
-        StreamClose closing(h, lk, stream, stream + 1);
-        if (!h->ended[stream] && h->fill[stream] == 0) { h->ended[stream] = 1; h->active[stream] = 0; }
-    }
+    // (whatever the file's length its stream is ended now -- nvx_stream_finish ends a stream that has had input -- so the next
+    // file on this stream needs its nvx_stream_reset and is never silently decoded as the continuation of this one; an
+    // empty file on a fresh stream ends nothing)
     return (int)((total + h->frame_in - 1) / h->frame_in);
 }
 

@@ -39,12 +39,11 @@ def test_reference_bits_reproduced_on_gpu(nv, name):
         for tag, chain in (("518", 0), ("490", 1)):
             assert p.bits(0, chain) == rec[f"bits{tag}"], f"{name}/{tag}"
         assert got_messages(p) == gold_messages(rec)
-        if iq.shape[0] % nv.FRAME_IN:                # the stream has ended: nothing more goes in until a reset
-            with pytest.raises(nv.NvxError):
-                p.push(0, iq[:100])
-            p.reset()
-            p.push(0, iq); p.finish()
-            assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
+        with pytest.raises(nv.NvxError):             # the stream has ended: nothing more goes in until a reset
+            p.push(0, iq[:100])
+        p.reset()
+        p.push(0, iq); p.finish()
+        assert p.bits(0, 0) == rec["bits518"] and p.bits(0, 1) == rec["bits490"]
 
 
 @pytest.mark.parametrize("name", ["ragged_length", "two_carrier", "weak_518"])
@@ -98,7 +97,7 @@ def test_tails_of_many_streams_in_one_launch_raw_rate_and_wideband(nv, oracle):
     """nvx_finish on handles with several streams whose inputs end at different places (one on a frame boundary, one too
     short for a single 900 S/s sample more): ONE launch carries every tail at its own length.  Both stage-0 forms at
     2.016 MS/s, and a wideband handle (8 sub-bands x 2 chains per input).  Every chain == the oracle on the same samples;
-    the stream that ended on a frame boundary goes on afterwards, the others are ended."""
+    every stream is ended afterwards -- the one that stopped on a frame boundary too (one rule for every length)."""
     import signals
     tails = [0, 2239, 2240, 100001, 300000, 645119]
     for order in (1, 3):
@@ -116,11 +115,10 @@ def test_tails_of_many_streams_in_one_launch_raw_rate_and_wideband(nv, oracle):
             for s in range(len(tails)):
                 assert (p.bits(s, 0), p.bits(s, 1)) == want[s], f"stage0 order {order}, stream {s}"
             for s, t in enumerate(tails):
-                if t == 0:
-                    p.push(s, np.zeros((16, 2), dtype=np.int16))          # not ended
-                else:
-                    with pytest.raises(nv.NvxError):
-                        p.push(s, np.zeros((16, 2), dtype=np.int16))
+                with pytest.raises(nv.NvxError):
+                    p.push(s, np.zeros((16, 2), dtype=np.int16))
+            p.stream_reset(0)                                             # (the one that stopped on a frame boundary starts anew like any other)
+            p.push(0, np.zeros((16, 2), dtype=np.int16))
     # wideband: two inputs, different tails
     wt = [7 * 2240 * 9 + 3, 400000]
     with nv.Pipeline(n_streams=2, wideband=True, chain_mask=3, max_frames=2, push_mode=True, char_layer=False) as p:
@@ -729,7 +727,7 @@ def test_a_stream_ended_under_a_running_capture_ring(nv, oracle):
                     time.sleep(0.0005)
                 nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap); pos += m
             p.push(1, iqs[1][k * nv.FRAME_IN:(k + 1) * nv.FRAME_IN])
-        m = 1234                                          # (a ragged end: a stream that stops ON a frame boundary is not ended by a finish)
+        m = 1234                                          # (a ragged end, as a radio's last callback leaves it)
         nv.lib.nvx_capture_callback(xi[pos:pos + m].ctypes.data, xq[pos:pos + m].ctypes.data, None, m, 0, cap); pos += m
         deadline = time.time() + 5.0
         while _stats(nv, cap)[2] < pos and time.time() < deadline:
