@@ -85,8 +85,9 @@ def test_a_sample_behind_shim_finish_starts_a_new_stream(nv, probe, tmp_path):
     assert got["bits518"][0] == got["bits518"][1] and len(got["bits518"][0]) > 20
 
 
+@pytest.mark.parametrize("power,blocks_before", [(31, 40), (32, 34)], ids=["2^31_int", "2^32_unsigned"])
 @pytest.mark.parametrize("max_frames", [1, 12], ids=["front_walk", "front_tiles"])
-def test_a_stream_walks_across_sample_2_to_31(nv, oracle, max_frames):
+def test_a_stream_walks_across_sample_2_to_31(nv, oracle, max_frames, power, blocks_before):
     """Deviation 3.  The reference's `int bd_seq_nbr` passes INT_MAX after 2^31 samples at 900 S/s = 27.6 days and its
     decoder falls silent (decoder.h:60, decoder.C:75,85; tests/test_deviations.py shows it on the compiled reference).
     Here the stream's sample clock is 64 bits wide everywhere it is used.  480 frames of signal, then the clock is put
@@ -94,9 +95,10 @@ def test_a_stream_walks_across_sample_2_to_31(nv, oracle, max_frames):
     else touched), then 24 more frames: the stream crosses sample 2 147 483 648 in the middle of a frame and every bit of
     both chains is the oracle's on the uninterrupted signal -- in both forms of the demodulator's front (the walk that
     short launches use, head + tiles for long launches of few chains).  The hook's own seal re-tag is judged by the
-    kernels: no launch failure, no repaired hand-over."""
+    kernels: no launch failure, no repaired hand-over.  The same across 2^32 (55 days), where an unsigned 32-bit count
+    would wrap."""
     import signals
-    block_frames, blocks_before, blocks_after = 12, 40, 2
+    block_frames, blocks_after = 12, 2
     b518, b490 = nv.sitor_encode(signals.stream_text(4242), 40), nv.sitor_encode(signals.stream_text(4243), 40)
     st = nv.make_stream([dict(freq_hz=14000, bits=b518, bit_offset=1201, phase0=77, amplitude=7000),
                          dict(freq_hz=-14000, bits=b490, bit_offset=333, phase0=99, amplitude=6000)], seed=4242, noise_amp=1500)
@@ -107,18 +109,18 @@ def test_a_stream_walks_across_sample_2_to_31(nv, oracle, max_frames):
             p.push(0, iq); ref.push(iq)
         p.flush()
         g = p.stream_stats(0)[1] * nv.FRAME_Y3
-        assert g == block_frames * blocks_before * nv.FRAME_Y3 == 138240
-        periods = (2 ** 31 - g) // p.CLOCK_PERIOD
+        assert g == block_frames * blocks_before * nv.FRAME_Y3
+        periods = (2 ** power - g) // p.CLOCK_PERIOD
         p.debug_advance_clock(0, periods)
         g_new = p.stream_stats(0)[1] * nv.FRAME_Y3
-        assert g_new == g + periods * p.CLOCK_PERIOD and 0 < 2 ** 31 - g_new < 11 * nv.FRAME_Y3
+        assert g_new == g + periods * p.CLOCK_PERIOD and 0 < 2 ** power - g_new < 11 * nv.FRAME_Y3
         for _k in range(blocks_after):
             p.push(0, iq); ref.push(iq)
         p.flush()
-        assert p.stream_stats(0)[1] * nv.FRAME_Y3 > 2 ** 31 + 12 * nv.FRAME_Y3       # well across
+        assert p.stream_stats(0)[1] * nv.FRAME_Y3 > 2 ** power + 12 * nv.FRAME_Y3       # well across
         for c in (0, 1):
             want = ref.bits(c)
-            assert len(want) > 16000 and p.bits(0, c) == want, f"chain {c}"
+            assert len(want) > 32 * block_frames * (blocks_before + blocks_after) - 100 and p.bits(0, c) == want, f"chain {c}"
         assert p.integrity_stats()[:2] == (0, 0)
 
 
