@@ -628,7 +628,18 @@ int nvx_collect_locked(nvx_handle *h, uint64_t upto)
             } else {
                 work(0, n_chains);
             }
-            if (bad_slot >= 0) { nvx_set_error("bit buffer overflow on slot %d", bad_slot.load()); return NVX_ERR_STATE; }
+            if (bad_slot >= 0) {
+                // A bit count outside what a launch can produce (it never has been: a bit takes at least eight samples): the
+                // result is not to be trusted and the other slots' bits of this launch are already appended -- taking the
+                // launch in AGAIN would append them twice.  So this sticks like a failed launch does.
+                h->poison_why = "a chain's bit count lay outside what a launch can produce (slot " + std::to_string(bad_slot.load()) + ")";
+                h->poisoned = true;
+                if (h->launch_done_valid) (void)hipEventSynchronize(h->launch_done);
+                for (auto &q : h->res) q.pending = false;
+                h->collected = h->launched;
+                nvx_set_error("%s; the results of this launch and of the launches queued behind it are discarded (nvx_reset the handle)", h->poison_why.c_str());
+                return NVX_ERR_HIP;
+            }
             for (int i = 0; i < h->n_slots; i++) if (!h->slots[i].outbox.empty()) deliver_outbox(h, i / 2, h->slots[i]);
             if (h->n_arrival) {
                 // live path: the frames of this launch are now decoded, pollable and their messages delivered
