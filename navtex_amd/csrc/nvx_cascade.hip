@@ -102,12 +102,14 @@ __device__ __forceinline__ double stage0_component(u32x4 v, bool odd)
 // (w[22] = w[23] = 0), and y[k] = A_k + B_(k-1) + C_(k-2).  Lanes as in the first-order form: the pair (2i, 2i+1) holds
 // block i of the load, four samples each; a lane sums both components of its four samples (v_perm de-interleaves them
 // into (x_i, x_i+1) half-word pairs -- its own component and the partner's, the selector is per lane -- and
-// v_dot2_i32_i16 multiplies a pair by a weight pair), keeps its own component and hands the other to its partner
-// (DPP pair swap).  The two block delays are two rotations of the wave by one lane pair (wave_ror:1 twice); lanes 62 / 63
-// of the rotated value come from the previous load, so that its last block lands in front of this load's first:
+// v_dot2_i32_i16 multiplies a pair by a weight pair): the partner's component first, which crosses to its owner by a DPP
+// pair swap, and the owner's own two dot products accumulate on top of what arrived.  The two block delays are two
+// rotations of the wave by one lane pair (wave_ror:1 twice); lanes 62 / 63 of the rotated value come from the previous
+// load, so that its last block lands in front of this load's first:
 //      t_b = B_b + C_(b-1),  y_b = A_b + t_(b-1).
-// 27 VALU instructions per load (first-order form: 11).  Carried between units: lanes 62 / 63 of (C, t) of the last
-// load, four integers, entry NVX_CASCADE_STATE_ENTRIES - 1 of the state block.
+// 29 VALU instructions per load as compiled (first-order form: 11; the round-2 form of step() below compiled to 34:
+// profiles/r06/c0_*).  Carried between units: lanes 62 / 63 of (C, t) of the last load, four integers, entry
+// NVX_CASCADE_STATE_ENTRIES - 1 of the state block.
 struct Stage0Cic3 {
     unsigned sel_mine, sel_other;            // v_perm selectors: low halves (I) or high halves (Q) of two words
     unsigned wa0, wa1, wb0, wb1, wc0, wc1;   // weight pairs of this lane's samples (0..3 on even lanes, 4..7 on odd ones)
@@ -127,17 +129,29 @@ struct Stage0Cic3 {
         c_prev = 0; t_prev = 0;
     }
     __device__ __forceinline__ static int rot1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }   // wave_ror:1: lane l reads lane l-1, lane 0 lane 63
+    // a dot product that STARTS a sum: the VOP3P form, whose third operand is the inline constant 0.  (The builtin with a
+    // zero accumulator compiles to v_mov_b32 acc, 0 + v_dot2c_i32_i16: six moves per load -- r6, counted in the ISA.)
+    __device__ __forceinline__ static int dot2_first(nvx_short2 a, unsigned w)
+    {
+        int r;
+        asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(w));
+        return r;
+    }
+    // r6: 29 vector instructions per load where the compiler had made 34 of the round-2 form (own sums and partner's sums
+    // side by side, three adds to join them: PMC 62.9 vector instructions per load in the kernel where the design counted
+    // 55.5; profiles/r06/c0_*).  Same integers, same sums mod 2^32, other grouping: the partner's three weighted sums first
+    // (the rounding constant rides on the first of them); each crosses to its owner by ONE DPP move, and the owner's own two
+    // dot products accumulate ON TOP of what arrived -- no separate add, no accumulator to clear.  Kernel -1.2 %.
     __device__ __forceinline__ double step(u32x4 v)
     {
         const nvx_short2 m01 = as_short2(__builtin_amdgcn_perm(v.y, v.x, sel_mine)), m23 = as_short2(__builtin_amdgcn_perm(v.w, v.z, sel_mine));
         const nvx_short2 o01 = as_short2(__builtin_amdgcn_perm(v.y, v.x, sel_other)), o23 = as_short2(__builtin_amdgcn_perm(v.w, v.z, sel_other));
-        int ma = __builtin_amdgcn_sdot2(m01, as_short2(wa0), 256, false); ma = __builtin_amdgcn_sdot2(m23, as_short2(wa1), ma, false);   // + 256: round half up
-        int mb = __builtin_amdgcn_sdot2(m01, as_short2(wb0), 0, false);   mb = __builtin_amdgcn_sdot2(m23, as_short2(wb1), mb, false);
-        int mc = __builtin_amdgcn_sdot2(m01, as_short2(wc0), 0, false);   mc = __builtin_amdgcn_sdot2(m23, as_short2(wc1), mc, false);
-        int oa = __builtin_amdgcn_sdot2(o01, as_short2(wa0), 0, false);   oa = __builtin_amdgcn_sdot2(o23, as_short2(wa1), oa, false);
-        int ob = __builtin_amdgcn_sdot2(o01, as_short2(wb0), 0, false);   ob = __builtin_amdgcn_sdot2(o23, as_short2(wb1), ob, false);
-        int oc = __builtin_amdgcn_sdot2(o01, as_short2(wc0), 0, false);   oc = __builtin_amdgcn_sdot2(o23, as_short2(wc1), oc, false);
-        const int A = ma + dpp_swap_pairs(oa), B = mb + dpp_swap_pairs(ob), C = mc + dpp_swap_pairs(oc);
+        int oa = __builtin_amdgcn_sdot2(o01, as_short2(wa0), 256, false); oa = __builtin_amdgcn_sdot2(o23, as_short2(wa1), oa, false);   // + 256: round half up
+        int ob = dot2_first(o01, wb0); ob = __builtin_amdgcn_sdot2(o23, as_short2(wb1), ob, false);
+        int oc = dot2_first(o01, wc0); oc = __builtin_amdgcn_sdot2(o23, as_short2(wc1), oc, false);
+        int A = dpp_swap_pairs(oa); A = __builtin_amdgcn_sdot2(m01, as_short2(wa0), A, false); A = __builtin_amdgcn_sdot2(m23, as_short2(wa1), A, false);
+        int B = dpp_swap_pairs(ob); B = __builtin_amdgcn_sdot2(m01, as_short2(wb0), B, false); B = __builtin_amdgcn_sdot2(m23, as_short2(wb1), B, false);
+        int C = dpp_swap_pairs(oc); C = __builtin_amdgcn_sdot2(m01, as_short2(wc0), C, false); C = __builtin_amdgcn_sdot2(m23, as_short2(wc1), C, false);
         const int t = B + rot1(rot1(last_pair ? c_prev : C));
         const int y = A + rot1(rot1(last_pair ? t_prev : t));
         c_prev = C; t_prev = t;

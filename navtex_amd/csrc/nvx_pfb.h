@@ -73,8 +73,10 @@ __device__ __forceinline__ void nvx_pfb_instant(const unsigned *win, int (&yr)[8
 __device__ __forceinline__ void nvx_pfb_instant_split(const unsigned *win, int c, int (&y)[8])
 {
     const int sh = 16 * c, sm = -c;                  // selector shift; sign mask: (v ^ sm) - sm = sigma * v
-    // the rounding constant of the branch sums starts in the accumulators: (sum + 16) >> 5
-    int u[8] = { 16, 16, 16, 16, 16, 16, 16, 16 };
+    // The rounding constant of the branch sums, (sum + 16) >> 5, rides on each branch's FIRST product: the VOP3P form of
+    // the dot product takes it as an inline constant.  (Accumulators that start at 16 compiled to eight v_mov_b32 per
+    // instant and component in front of the v_dot2c chain: r6, counted in the ISA, tests/test_isa.py.)
+    int u[8];
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         const u32x4 w = *(const u32x4 *)&win[4 * r];
@@ -83,7 +85,8 @@ __device__ __forceinline__ void nvx_pfb_instant_split(const unsigned *win, int c
         for (int e = 0; e < 4; e++) {
             const int j = 4 * r + e;
             const unsigned hs = ((unsigned)(unsigned short)NVX_PFB_H[47 - j]) << sh;
-            u[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), as_short2(hs), u[j & 7], false);
+            if (j < 8) asm("v_dot2_i32_i16 %0, %1, %2, 16" : "=v"(u[j]) : "v"(ww[e]), "v"(hs));
+            else u[j & 7] = __builtin_amdgcn_sdot2(as_short2(ww[e]), as_short2(hs), u[j & 7], false);
         }
     }
 #pragma unroll

@@ -57,6 +57,7 @@ def test_channeliser_phase_instruction_count_behind_the_bench_lines_decompositio
     dots = [i for i, l in enumerate(lines) if l.startswith("v_dot2")]
     bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
     assert len(dots) == 48                               # one (tap, sample) product per instruction: 48 taps
+    assert sum(1 for i in dots if lines[i].startswith("v_dot2_i32_i16")) == 8      # each branch's first product carries the rounding constant (VOP3P, inline 16): no accumulator to clear
     lo, hi = max(b for b in bars if b < dots[0]), min(b for b in bars if b > dots[-1])
     phase = lines[lo:hi]
     valu = sum(1 for l in phase if l.startswith("v_"))

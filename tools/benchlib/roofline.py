@@ -33,12 +33,13 @@ WB_SHARE_CASCADE = round(1 - 6.470 / 17.889, 3)         # 0.638: FIR1, mixers, F
 WB_SHARE_CHANNELISER = round(1 - 14.141 / 17.889, 3)    # 0.210: integer arithmetic that earns no fp64 credit
 WB_SHARE_BARRIERS = round(1 - 16.642 / 17.889, 3)       # 0.070
 # Vector instructions of the channeliser phase (nvx_pfb.h, nvx_pfb_instant_split: a lane pair per output instant, one
-# component each), counted in the compiled kernel between its two barriers (tests/test_isa.py holds the count): 128 per
-# (instant, component) -- 48 v_dot2c_i32_i16 (one tap on one sample each), 16 shifts, 27 adds / subs, 8 v_med3 clamps, 8
-# v_cvt_f64_i32, 8 moves, 5 DPP exchanges with the partner lane, two 64-bit products for the 45-degree twiddles -- beside 12
-# ds_read_b128 and 8 ds_write_b64; two components, eight raw samples per instant.
-WB_CHANNELISER_VALU_PER_LANE = 128
-WB_INT_OPS_PER_RAW_SAMPLE = WB_CHANNELISER_VALU_PER_LANE * 2 / 8          # 32
+# component each), counted in the compiled kernel between its two barriers (tests/test_isa.py holds the count): 120 per
+# (instant, component) -- 48 dot products (one tap on one sample each), 16 shifts, 27 adds / subs, 8 v_med3 clamps, 8
+# v_cvt_f64_i32, 5 DPP exchanges with the partner lane, two 64-bit products for the 45-degree twiddles -- beside 12
+# ds_read_b128 and 8 ds_write_b64; two components, eight raw samples per instant.  (128 until r6: eight moves cleared
+# accumulators that the VOP3P form of a branch's first product does not need; kernel -0.8 %, profiles/r06/c1_*.)
+WB_CHANNELISER_VALU_PER_LANE = 120
+WB_INT_OPS_PER_RAW_SAMPLE = WB_CHANNELISER_VALU_PER_LANE * 2 / 8          # 30
 
 
 def wideband_decomposition(frac, fps):
@@ -55,7 +56,7 @@ def wideband_decomposition(frac, fps):
             "channeliser_int_ops_per_raw_sample": WB_INT_OPS_PER_RAW_SAMPLE,
             "valu_issue_frac_counting_integer_ops": round(frac * (fps + WB_INT_OPS_PER_RAW_SAMPLE) / fps, 4),
             "reading": "the phases of a pass add (barriers between them): the cascade pass, which does ALL the credited fp64 operations, takes 64 % of the kernel and "
-                       "alone runs at cascade_pass_frac_of_fp64_roof (about variant_a's efficiency); the channeliser's ~32 integer vector instructions per raw "
+                       "alone runs at cascade_pass_frac_of_fp64_roof (about variant_a's efficiency); the channeliser's ~30 integer vector instructions per raw "
                        "sample cost the same issue slots as fp64 ones and earn no credit -- counted like fp64 operations the kernel issues at "
                        "valu_issue_frac_counting_integer_ops of the roof"}
 
