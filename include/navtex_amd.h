@@ -241,7 +241,7 @@ typedef struct nvx_config {
                               /*   out = (sum + 4) >> 3 (25 dB of alias rejection at the NAVTEX offsets);             */
                               /* 3: three such boxcars in cascade (a third-order CIC as its 22-tap FIR,               */
                               /*   w = 1 3 6 10 15 21 28 36 42 46 48 48 46 ... 3 1):  out = (sum w x + 256) >> 9,     */
-                              /*   76 dB of alias rejection, 14 samples of carried history, ~8 % more kernel time.    */
+                              /*   76 dB of alias rejection, 14 samples of carried history, ~2 % more kernel time.    */
                               /* Both are build-owned integer definitions (the reference starts at 252 kS/s:          */
                               /* receiver/capt_sched.c:31-34); anything else is NVX_ERR_ARG.                           */
     int      eager_launch;    /* push_mode = 1 only.  0: a launch goes out when EVERY active stream has a whole frame  */
